@@ -1,0 +1,240 @@
+// ggs_api.hip -- the extern "C" boundary of libggsplat.so (see include/ggsplat.h).
+// Host-side only: argument checks, workspace carving, kernel launches on the caller's
+// stream.  No allocation, no synchronisation (unless GgsParams.debug), no exceptions.
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "ggs_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// After each launch: always catch launch errors; in debug mode also sync and catch execution errors.
+int check(const char* what, hipStream_t s, int debug) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GGS_ERR_HIP, "%s: launch failed: %s", what, hipGetErrorString(e));
+    if (debug) {
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return fail(GGS_ERR_HIP, "%s: execution failed: %s", what, hipGetErrorString(e));
+    }
+    return GGS_OK;
+}
+
+#define GGS_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__ != GGS_OK) return rc__; \
+    } while (0)
+
+int check_params(const GgsParams* p) {
+    if (!p) return fail(GGS_ERR_ARG, "params is NULL");
+    if (p->P < 0 || p->W <= 0 || p->H <= 0 || p->n_views <= 0)
+        return fail(GGS_ERR_ARG, "bad sizes P=%d W=%d H=%d n_views=%d", p->P, p->W, p->H, p->n_views);
+    if (p->n_views > 65535) return fail(GGS_ERR_SIZE, "n_views=%d exceeds the grid.y limit 65535", p->n_views);
+    if ((size_t)p->P * (size_t)p->n_views > (size_t)1 << 40) return fail(GGS_ERR_SIZE, "P*n_views too large");
+    return GGS_OK;
+}
+
+int check_modes(const GgsParams* p, const void* shs, const void* colors, const void* scales, const void* rots,
+                const void* cov) {
+    if ((shs != nullptr) == (colors != nullptr))
+        return fail(GGS_ERR_ARG, "Please provide excatly one of either SHs or precomputed colors!");
+    if (((scales != nullptr) || (rots != nullptr)) == (cov != nullptr) || ((scales != nullptr) != (rots != nullptr)))
+        return fail(GGS_ERR_ARG, "Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!");
+    if (shs) {
+        if (p->sh_degree < 0 || p->sh_degree > 3) return fail(GGS_ERR_ARG, "sh_degree=%d not in 0..3", p->sh_degree);
+        if ((p->sh_degree + 1) * (p->sh_degree + 1) > p->K)
+            return fail(GGS_ERR_ARG, "sh_degree=%d needs %d coefficients, shs has K=%d", p->sh_degree,
+                        (p->sh_degree + 1) * (p->sh_degree + 1), p->K);
+    }
+    return GGS_OK;
+}
+
+struct Dims { int gx, gy, T; };
+Dims dims(const GgsParams* p) {
+    Dims d;
+    d.gx = (p->W + GGS_TILE - 1) / GGS_TILE;
+    d.gy = (p->H + GGS_TILE - 1) / GGS_TILE;
+    d.T = d.gx * d.gy;
+    return d;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* ggs_last_error(void) { return g_err; }
+const char* ggs_version(void) { return "ggsplat 0.1 gfx950"; }
+
+int ggs_workspace_sizes(const GgsParams* p, size_t bin_capacity, size_t* geom_bytes, size_t* img_bytes,
+                        size_t* bin_bytes) {
+    GGS_TRY(check_params(p));
+    const Dims d = dims(p);
+    const size_t V = (size_t)p->n_views;
+    if (geom_bytes) *geom_bytes = ggs_align(V * (size_t)p->P * sizeof(SplatRec));
+    if (img_bytes) *img_bytes = ggs_align(V * (size_t)p->W * p->H * 4) * 2;
+    if (bin_bytes) *bin_bytes = ggs_bin_layout(p->n_views, d.T, bin_capacity).total;
+    return GGS_OK;
+}
+
+int ggs_bin_layout(const GgsParams* p, size_t bin_capacity, size_t offsets[8]) {
+    GGS_TRY(check_params(p));
+    if (!offsets) return fail(GGS_ERR_ARG, "offsets is NULL");
+    const BinLayout L = ggs_bin_layout(p->n_views, dims(p).T, bin_capacity);
+    offsets[0] = L.header; offsets[1] = L.tile_count; offsets[2] = L.tile_cursor; offsets[3] = L.tile_offset;
+    offsets[4] = L.view_base; offsets[5] = L.keys; offsets[6] = L.ids; offsets[7] = L.total;
+    return GGS_OK;
+}
+
+size_t ggs_backward_scratch_bytes(const GgsParams* p) {
+    if (!p || p->P < 0 || p->n_views <= 0) return 0;
+    return ggs_align((size_t)p->n_views * (size_t)p->P * sizeof(GradRec));
+}
+
+int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const float* shs,
+                const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                const float* cov3D_precomp, const float* view, const float* proj, const float* campos,
+                const float* tanfov, void* geom, void* bin, size_t bin_capacity, void* img, float* out_color,
+                float* out_depth, float* out_alpha, int* radii, void* stream_) {
+    g_err[0] = 0;
+    GGS_TRY(check_params(p));
+    GGS_TRY(check_modes(p, shs, colors_precomp, scales, rotations, cov3D_precomp));
+    if (!bg || !view || !proj || !campos || !tanfov || !geom || !bin || !img || !out_color || !out_depth ||
+        !out_alpha || (p->P > 0 && (!means3D || !opacities || !radii)))
+        return fail(GGS_ERR_ARG, "ggs_forward: NULL pointer argument");
+    hipStream_t s = (hipStream_t)stream_;
+    const Dims d = dims(p);
+    const int V = p->n_views;
+    const BinLayout L = ggs_bin_layout(V, d.T, bin_capacity);
+    char* b = (char*)bin;
+    GgsBinHeader* header = (GgsBinHeader*)(b + L.header);
+    uint32_t* tile_count = (uint32_t*)(b + L.tile_count);
+    uint32_t* tile_cursor = (uint32_t*)(b + L.tile_cursor);
+    uint32_t* tile_offset = (uint32_t*)(b + L.tile_offset);
+    unsigned long long* view_base = (unsigned long long*)(b + L.view_base);
+    unsigned long long* keys = (unsigned long long*)(b + L.keys);
+    uint32_t* ids = (uint32_t*)(b + L.ids);
+    const size_t HW = (size_t)p->W * p->H;
+    float* final_T = (float*)img;
+    uint32_t* n_contrib = (uint32_t*)((char*)img + ggs_align((size_t)V * HW * 4));
+
+    if (hipMemsetAsync(bin, 0, L.zero_bytes, s) != hipSuccess)
+        return fail(GGS_ERR_HIP, "ggs_forward: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
+
+    const dim3 gridP((unsigned)((p->P + 255) / 256), (unsigned)V);
+    if (p->P > 0) {
+        PreArgs a;
+        a.P = p->P; a.K = p->K; a.deg = p->sh_degree; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T;
+        a.scale_modifier = p->scale_modifier;
+        a.means3D = means3D; a.shs = shs; a.colors = colors_precomp; a.opacities = opacities;
+        a.scales = scales; a.rots = rotations; a.cov3d = cov3D_precomp;
+        a.view = view; a.proj = proj; a.campos = campos; a.tanfov = tanfov;
+        a.rec = (SplatRec*)geom; a.radii = radii; a.tile_count = tile_count;
+        hipLaunchKernelGGL(ggs_k_preprocess, gridP, dim3(256), 0, s, a);
+        GGS_TRY(check("preprocess", s, p->debug));
+    }
+    {
+        ScanArgs a;
+        a.T = d.T; a.capacity = (unsigned long long)bin_capacity; a.tile_count = tile_count;
+        a.tile_offset = tile_offset; a.view_base = view_base; a.header = header;
+        hipLaunchKernelGGL(ggs_k_scan_tiles, dim3((unsigned)V), dim3(1024), 0, s, a);
+        GGS_TRY(check("scan_tiles", s, p->debug));
+    }
+    if (p->P > 0) {
+        ScatterArgs a;
+        a.P = p->P; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.rec = (const SplatRec*)geom; a.header = header;
+        a.tile_cursor = tile_cursor; a.tile_offset = tile_offset; a.view_base = view_base; a.keys = keys;
+        hipLaunchKernelGGL(ggs_k_scatter, gridP, dim3(256), 0, s, a);
+        GGS_TRY(check("scatter", s, p->debug));
+    }
+    const dim3 gridT((unsigned)d.T, (unsigned)V);
+    {
+        SortArgs a;
+        a.T = d.T; a.header = header; a.tile_count = tile_count; a.tile_offset = tile_offset;
+        a.view_base = view_base; a.keys = keys; a.ids = ids;
+        hipLaunchKernelGGL(ggs_k_sort_tiles, gridT, dim3(256), 0, s, a);
+        GGS_TRY(check("sort_tiles", s, p->debug));
+    }
+    {
+        RenderArgs a;
+        a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.header = header;
+        a.tile_count = tile_count; a.tile_offset = tile_offset; a.view_base = view_base; a.ids = ids;
+        a.rec = (const SplatRec*)geom; a.bg = bg; a.out_color = out_color; a.out_depth = out_depth;
+        a.out_alpha = out_alpha; a.final_T = final_T; a.n_contrib = n_contrib;
+        hipLaunchKernelGGL(ggs_k_render_fwd, gridT, dim3(256), 0, s, a);
+        GGS_TRY(check("render_fwd", s, p->debug));
+    }
+    return GGS_OK;
+}
+
+int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* scales, const float* rotations,
+                 const float* cov3D_precomp, const float* view, const float* proj, const float* campos,
+                 const float* tanfov, const void* geom, const void* bin, size_t bin_capacity,
+                 const void* img, const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch,
+                 float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs, float* dL_dcolors,
+                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, int accumulate, void* stream_) {
+    g_err[0] = 0;
+    GGS_TRY(check_params(p));
+    GGS_TRY(check_modes(p, shs, colors_precomp, scales, rotations, cov3D_precomp));
+    if (!bg || !view || !proj || !campos || !tanfov || !geom || !bin || !img || !dL_dcolor || !scratch)
+        return fail(GGS_ERR_ARG, "ggs_backward: NULL pointer argument");
+    if (p->P == 0) return GGS_OK;
+    if (!means3D || !dL_dmeans3D || !dL_dopacities) return fail(GGS_ERR_ARG, "ggs_backward: NULL gradient output");
+    if (shs && !dL_dshs) return fail(GGS_ERR_ARG, "ggs_backward: dL_dshs is NULL but shs given");
+    if (colors_precomp && !dL_dcolors) return fail(GGS_ERR_ARG, "ggs_backward: dL_dcolors is NULL but colors given");
+    if (cov3D_precomp && !dL_dcov3D) return fail(GGS_ERR_ARG, "ggs_backward: dL_dcov3D is NULL but cov3D given");
+    if (scales && (!dL_dscales || !dL_drotations))
+        return fail(GGS_ERR_ARG, "ggs_backward: dL_dscales / dL_drotations is NULL but scales given");
+    hipStream_t s = (hipStream_t)stream_;
+    const Dims d = dims(p);
+    const int V = p->n_views;
+    const BinLayout L = ggs_bin_layout(V, d.T, bin_capacity);
+    const char* b = (const char*)bin;
+    const size_t HW = (size_t)p->W * p->H;
+
+    if (hipMemsetAsync(scratch, 0, (size_t)V * p->P * sizeof(GradRec), s) != hipSuccess)
+        return fail(GGS_ERR_HIP, "ggs_backward: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
+    {
+        RenderBwdArgs a;
+        a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T;
+        a.tile_count = (const uint32_t*)(b + L.tile_count);
+        a.tile_offset = (const uint32_t*)(b + L.tile_offset);
+        a.view_base = (const unsigned long long*)(b + L.view_base);
+        a.ids = (const uint32_t*)(b + L.ids);
+        a.rec = (const SplatRec*)geom; a.bg = bg;
+        a.final_T = (const float*)img;
+        a.n_contrib = (const uint32_t*)((const char*)img + ggs_align((size_t)V * HW * 4));
+        a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth; a.dL_dalpha = dL_dalpha;
+        a.acc = (GradRec*)scratch;
+        const dim3 gridT((unsigned)d.T, (unsigned)V);
+        if (dL_ddepth || dL_dalpha) hipLaunchKernelGGL(ggs_k_render_bwd_da, gridT, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(ggs_k_render_bwd, gridT, dim3(256), 0, s, a);
+        GGS_TRY(check("render_bwd", s, p->debug));
+    }
+    {
+        PreBwdArgs a;
+        a.P = p->P; a.K = p->K; a.deg = p->sh_degree; a.W = p->W; a.H = p->H; a.V = V; a.accumulate = accumulate;
+        a.scale_modifier = p->scale_modifier;
+        a.means3D = means3D; a.shs = shs; a.colors = colors_precomp; a.scales = scales; a.rots = rotations;
+        a.cov3d = cov3D_precomp; a.view = view; a.proj = proj; a.campos = campos; a.tanfov = tanfov;
+        a.rec = (const SplatRec*)geom; a.acc = (const GradRec*)scratch;
+        a.dL_dmeans2D = dL_dmeans2D; a.dL_dmeans3D = dL_dmeans3D; a.dL_dopac = dL_dopacities; a.dL_dsh = dL_dshs;
+        a.dL_dcolors = dL_dcolors; a.dL_dscales = dL_dscales; a.dL_drots = dL_drotations; a.dL_dcov3D = dL_dcov3D;
+        hipLaunchKernelGGL(ggs_k_preprocess_bwd, dim3((unsigned)((p->P + 255) / 256)), dim3(256), 0, s, a);
+        GGS_TRY(check("preprocess_bwd", s, p->debug));
+    }
+    return GGS_OK;
+}
+
+}  // extern "C"

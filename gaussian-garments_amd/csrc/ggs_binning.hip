@@ -1,0 +1,116 @@
+// ggs_binning.hip -- per-view tile-histogram scan and per-tile key sort.
+//
+// Binning on MI355X is organised around the 160 KB LDS instead of a global radix
+// sort: splats are first dropped, unsorted, into their tile's segment (atomic slot
+// allocation, ggs_k_scatter), then every tile sorts its own segment in LDS.  The
+// whole pipeline moves each (splat, tile) key through HBM once in and once out
+// (N * (8 + 8 + 4) B) instead of the ~6 read+write passes of an LSD radix sort
+// over 64-bit keys.  Roofline: HBM for the traffic, but the sort itself is
+// LDS/barrier bound.
+#include "ggs_kernels.h"
+
+// K2: grid V, block 1024.  Exclusive scan of tile_count[v][:] -> tile_offset[v][:],
+// view total -> claims a segment [view_base, view_base + total) of the key buffer.
+__global__ __launch_bounds__(1024) void ggs_k_scan_tiles(ScanArgs a) {
+    const int v = blockIdx.x;
+    const int tid = threadIdx.x;
+    const uint32_t* cnt = a.tile_count + (size_t)v * a.T;
+    uint32_t* off = a.tile_offset + (size_t)v * a.T;
+    const int per = (a.T + 1023) / 1024;
+    const int t0 = tid * per;
+    uint32_t local = 0;
+    for (int i = 0; i < per; ++i)
+        if (t0 + i < a.T) local += cnt[t0 + i];
+    // inclusive scan inside each wave64, then across the 16 waves
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t x = local;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t y = __shfl_up(x, d);
+        if (lane >= d) x += y;
+    }
+    __shared__ uint32_t wsum[16];
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) wbase += wsum[w];
+        total += wsum[w];
+    }
+    uint32_t run = wbase + x - local;
+    for (int i = 0; i < per; ++i)
+        if (t0 + i < a.T) {
+            off[t0 + i] = run;
+            run += cnt[t0 + i];
+        }
+    if (tid == 0) {
+        const unsigned long long base = atomicAdd(&a.header->num_rendered, (unsigned long long)total);
+        a.view_base[v] = base;
+        if (base + total > a.capacity) atomicExch(&a.header->overflow, 1ull);
+    }
+}
+
+namespace {
+
+// Ascending-only bitonic network over `n2` = 2^m >= L slots; slots >= L are virtual +inf
+// keys, so a compare-exchange whose upper partner is >= L is a no-op.
+template <typename KeyPtr>
+__device__ __forceinline__ void bitonic_sort(KeyPtr key, int L, int n2, int tid, int nthreads) {
+    for (int k = 2; k <= n2; k <<= 1) {
+        // flip step: partner = mirror inside the block of size k
+        const int hk = k >> 1;
+        for (int t = tid; t < (n2 >> 1); t += nthreads) {
+            const int blk = t / hk, o = t - blk * hk;
+            const int i = blk * k + o, p = blk * k + k - 1 - o;
+            if (p < L) {
+                const unsigned long long a = key[i], b = key[p];
+                if (a > b) { key[i] = b; key[p] = a; }
+            }
+        }
+        __syncthreads();
+        for (int j = k >> 2; j > 0; j >>= 1) {
+            for (int t = tid; t < (n2 >> 1); t += nthreads) {
+                const int i = ((t / j) * (j << 1)) + (t % j), p = i + j;
+                if (p < L) {
+                    const unsigned long long a = key[i], b = key[p];
+                    if (a > b) { key[i] = b; key[p] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+}  // namespace
+
+// K4a: grid (T, V), block 256.  Sorts the tile's key segment by (depth bits, id) and
+// writes the id list the render kernels walk.
+__global__ __launch_bounds__(256) void ggs_k_sort_tiles(SortArgs a) {
+    if (a.header->overflow) return;
+    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
+    const int L = (int)a.tile_count[(size_t)v * a.T + t];
+    if (L == 0) return;
+    const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
+    unsigned long long* keys = a.keys + base;
+    uint32_t* ids = a.ids + base;
+    if (L == 1) {
+        if (tid == 0) ids[0] = (uint32_t)keys[0];
+        return;
+    }
+    int n2 = 2;
+    while (n2 < L) n2 <<= 1;
+    __shared__ unsigned long long s_key[GGS_SORT_CAP];
+    if (L <= GGS_SORT_CAP) {
+        for (int i = tid; i < L; i += 256) s_key[i] = keys[i];
+        __syncthreads();
+        bitonic_sort(s_key, L, n2, tid, 256);
+        for (int i = tid; i < L; i += 256) ids[i] = (uint32_t)s_key[i];
+    } else {
+        // Oversized list (pathological: > 4096 splats on one 16x16 tile): same network on the
+        // global segment.  Slow but exact; plain loads/stores are ordered by __syncthreads
+        // inside one workgroup (same CU, same L1).
+        bitonic_sort(keys, L, n2, tid, 256);
+        for (int i = tid; i < L; i += 256) ids[i] = (uint32_t)keys[i];
+    }
+}

@@ -1,0 +1,175 @@
+// ggs_common.h -- shared device-side definitions of libggsplat (gfx950 only).
+//
+// HBM layouts (all per call, caller-allocated, see include/ggsplat.h):
+//   geom : SplatRec rec[V][P]            48 B per (view, Gaussian), AoS so that the
+//                                        render kernels gather one record = 3 x 16 B
+//                                        from one or two cache lines.
+//   bin  : BinHeader | tile_count[V][T] | tile_cursor[V][T] | tile_offset[V][T] |
+//          view_base[V] | keys[cap] (u64: depth bits << 32 | Gaussian id) | ids[cap] (u32)
+//   img  : final_T[V][H*W] f32 | n_contrib[V][H*W] u32
+//   bwd scratch : GradRec acc[V][P]      48 B per (view, Gaussian), atomically accumulated
+//                                        per-Gaussian screen-space gradients.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/ggsplat.h"
+
+#define GGS_TILE 16
+#define GGS_BLOCK 256            // threads per render block = one 16x16 tile = 4 wave64
+#define GGS_BATCH 256            // splats staged in LDS per round
+#define GGS_SORT_CAP 4096        // per-tile list length sorted in LDS (above: global fallback)
+
+// Constants of the algorithm, one line each.
+#define GGS_NEAR_Z 0.2f
+#define GGS_W_EPS 0.0000001f
+#define GGS_FOV_CLAMP 1.3f
+#define GGS_LOWPASS 0.3f
+#define GGS_LAMBDA_FLOOR 0.1f
+#define GGS_ALPHA_MAX 0.99f
+#define GGS_ALPHA_MIN (1.0f / 255.0f)
+#define GGS_T_MIN 0.0001f
+#define GGS_DET_EPS 0.0000001f
+
+struct SplatRec {                // float index
+    float px, py, cx, cy;        // 0..3   pixel mean, conic.x, conic.y
+    float cz, opacity, r, g;     // 4..7   conic.z, opacity, colour r, g
+    float b, depth;              // 8..9   colour b, view-space depth
+    int radius;                  // 10     3-sigma radius in px; 0 = culled
+    unsigned clamped;            // 11     bit c set: SH colour channel c was clamped at 0
+};
+static_assert(sizeof(SplatRec) == 48, "SplatRec must be 48 bytes");
+
+struct GradRec {                 // per-(view, Gaussian) gradient accumulators
+    float mx, my;                // d/d(pixel mean)
+    float cx, cy, cz;            // d/d(conic)   (cy = true off-diagonal derivative)
+    float opacity;
+    float r, g, b;
+    float depth;
+    float pad0, pad1;
+};
+static_assert(sizeof(GradRec) == 48, "GradRec must be 48 bytes");
+
+struct BinLayout {               // byte offsets inside the binning buffer
+    size_t header, tile_count, tile_cursor, tile_offset, view_base, keys, ids, total;
+    size_t zero_bytes;           // header + tile_count + tile_cursor are cleared each forward
+};
+
+static inline size_t ggs_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+static inline BinLayout ggs_bin_layout(int V, int T, size_t cap) {
+    BinLayout L;
+    size_t o = 0;
+    L.header = o;      o += ggs_align(sizeof(GgsBinHeader));
+    L.tile_count = o;  o += ggs_align((size_t)V * T * 4);
+    L.tile_cursor = o; o += ggs_align((size_t)V * T * 4);
+    L.zero_bytes = o;
+    L.tile_offset = o; o += ggs_align((size_t)V * T * 4);
+    L.view_base = o;   o += ggs_align((size_t)V * 8);
+    L.keys = o;        o += ggs_align(cap * 8);
+    L.ids = o;         o += ggs_align(cap * 4);
+    L.total = o;
+    return L;
+}
+
+#ifdef __HIPCC__
+__device__ __forceinline__ float ggs_min(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float ggs_max(float a, float b) { return a > b ? a : b; }
+
+// Tile rectangle of a splat (A.1 step 6); must be bit-identical wherever it is recomputed.
+__device__ __forceinline__ void ggs_tile_rect(float px, float py, float r, int gx, int gy, int& x0, int& y0,
+                                              int& x1, int& y1) {
+    int a0 = (int)((px - r) / (float)GGS_TILE), b0 = (int)((py - r) / (float)GGS_TILE);
+    int a1 = (int)((px + r + (float)(GGS_TILE - 1)) / (float)GGS_TILE);
+    int b1 = (int)((py + r + (float)(GGS_TILE - 1)) / (float)GGS_TILE);
+    x0 = a0 < 0 ? 0 : (a0 > gx ? gx : a0);
+    y0 = b0 < 0 ? 0 : (b0 > gy ? gy : b0);
+    x1 = a1 < 0 ? 0 : (a1 > gx ? gx : a1);
+    y1 = b1 < 0 ? 0 : (b1 > gy ? gy : b1);
+}
+
+// Rotation matrix (row-major) of a (w,x,y,z) quaternion, no normalisation (A.0).
+__device__ __forceinline__ void ggs_quat_R(const float* q, float* R) {
+    float r = q[0], x = q[1], y = q[2], z = q[3];
+    R[0] = 1.f - 2.f * (y * y + z * z); R[1] = 2.f * (x * y - r * z); R[2] = 2.f * (x * z + r * y);
+    R[3] = 2.f * (x * y + r * z); R[4] = 1.f - 2.f * (x * x + z * z); R[5] = 2.f * (y * z - r * x);
+    R[6] = 2.f * (x * z - r * y); R[7] = 2.f * (y * z + r * x); R[8] = 1.f - 2.f * (x * x + y * y);
+}
+
+// Sigma = R S^2 R^T as (xx,xy,xz,yy,yz,zz) via M[k][i] = s_k R[i][k].
+__device__ __forceinline__ void ggs_cov3d(const float* scale, float mod, const float* q, float* c6) {
+    float R[9], M[9];
+    ggs_quat_R(q, R);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        float s = mod * scale[k];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) M[k * 3 + i] = s * R[i * 3 + k];
+    }
+    c6[0] = M[0] * M[0] + M[3] * M[3] + M[6] * M[6];
+    c6[1] = M[0] * M[1] + M[3] * M[4] + M[6] * M[7];
+    c6[2] = M[0] * M[2] + M[3] * M[5] + M[6] * M[8];
+    c6[3] = M[1] * M[1] + M[4] * M[4] + M[7] * M[7];
+    c6[4] = M[1] * M[2] + M[4] * M[5] + M[7] * M[8];
+    c6[5] = M[2] * M[2] + M[5] * M[5] + M[8] * M[8];
+}
+
+// EWA projection pieces shared by forward and backward (A.1 step 4).
+struct Ewa { float tx, ty, tz, fx, fy, xmul, ymul, M[6]; };
+
+__device__ __forceinline__ void ggs_ewa(const float* view, const float* m, float tanfovx, float tanfovy, int W,
+                                        int H, Ewa& e) {
+    float t0 = view[0] * m[0] + view[4] * m[1] + view[8] * m[2] + view[12];
+    float t1 = view[1] * m[0] + view[5] * m[1] + view[9] * m[2] + view[13];
+    float t2 = view[2] * m[0] + view[6] * m[1] + view[10] * m[2] + view[14];
+    float limx = GGS_FOV_CLAMP * tanfovx, limy = GGS_FOV_CLAMP * tanfovy;
+    float txtz = t0 / t2, tytz = t1 / t2;
+    e.xmul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+    e.ymul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+    e.tx = ggs_min(limx, ggs_max(-limx, txtz)) * t2;
+    e.ty = ggs_min(limy, ggs_max(-limy, tytz)) * t2;
+    e.tz = t2;
+    e.fx = (float)W / (2.f * tanfovx);
+    e.fy = (float)H / (2.f * tanfovy);
+    float j00 = e.fx / e.tz, j02 = -(e.fx * e.tx) / (e.tz * e.tz);
+    float j11 = e.fy / e.tz, j12 = -(e.fy * e.ty) / (e.tz * e.tz);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        e.M[j] = j00 * view[4 * j + 0] + j02 * view[4 * j + 2];
+        e.M[3 + j] = j11 * view[4 * j + 1] + j12 * view[4 * j + 2];
+    }
+}
+
+__device__ __forceinline__ void ggs_sym6_mul(const float* c6, const float* v, float* o) {
+    o[0] = c6[0] * v[0] + c6[1] * v[1] + c6[2] * v[2];
+    o[1] = c6[1] * v[0] + c6[3] * v[1] + c6[4] * v[2];
+    o[2] = c6[2] * v[0] + c6[4] * v[1] + c6[5] * v[2];
+}
+
+// SH basis (degree <= 3), same polynomials / constants as utils/sh_utils.py:25-111.
+#define GGS_SH_C0 0.28209479177387814f
+#define GGS_SH_C1 0.4886025119029199f
+template <int DEG>
+__device__ __forceinline__ void ggs_sh_basis(const float* d, float* b) {
+    b[0] = GGS_SH_C0;
+    if constexpr (DEG > 0) {
+        float x = d[0], y = d[1], z = d[2];
+        b[1] = -GGS_SH_C1 * y; b[2] = GGS_SH_C1 * z; b[3] = -GGS_SH_C1 * x;
+        if constexpr (DEG > 1) {
+            float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            b[4] = 1.0925484305920792f * xy; b[5] = -1.0925484305920792f * yz;
+            b[6] = 0.31539156525252005f * (2.f * zz - xx - yy);
+            b[7] = -1.0925484305920792f * xz; b[8] = 0.5462742152960396f * (xx - yy);
+            if constexpr (DEG > 2) {
+                b[9] = -0.5900435899266435f * y * (3.f * xx - yy);
+                b[10] = 2.890611442640554f * xy * z;
+                b[11] = -0.4570457994644658f * y * (4.f * zz - xx - yy);
+                b[12] = 0.3731763325901154f * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                b[13] = -0.4570457994644658f * x * (4.f * zz - xx - yy);
+                b[14] = 1.445305721320277f * z * (xx - yy);
+                b[15] = -0.5900435899266435f * x * (xx - 3.f * yy);
+            }
+        }
+    }
+}
+#endif  // __HIPCC__

@@ -1,0 +1,93 @@
+// ggs_kernels.h -- kernel argument blocks and declarations (internal).
+#pragma once
+#include "ggs_common.h"
+
+struct PreArgs {
+    int P, K, deg, W, H, gx, gy, T;
+    float scale_modifier;
+    const float *means3D, *shs, *colors, *opacities, *scales, *rots, *cov3d;
+    const float *view, *proj, *campos, *tanfov;
+    SplatRec* rec;
+    int* radii;
+    uint32_t* tile_count;
+};
+
+struct ScanArgs {
+    int T;
+    unsigned long long capacity;
+    const uint32_t* tile_count;
+    uint32_t* tile_offset;
+    unsigned long long* view_base;
+    GgsBinHeader* header;
+};
+
+struct ScatterArgs {
+    int P, gx, gy, T;
+    const SplatRec* rec;
+    const GgsBinHeader* header;
+    uint32_t* tile_cursor;
+    const uint32_t* tile_offset;
+    const unsigned long long* view_base;
+    unsigned long long* keys;
+};
+
+struct SortArgs {
+    int T;
+    const GgsBinHeader* header;
+    const uint32_t* tile_count;
+    const uint32_t* tile_offset;
+    const unsigned long long* view_base;
+    unsigned long long* keys;
+    uint32_t* ids;
+};
+
+struct RenderArgs {
+    int P, W, H, gx, gy, T;
+    const GgsBinHeader* header;
+    const uint32_t* tile_count;
+    const uint32_t* tile_offset;
+    const unsigned long long* view_base;
+    const uint32_t* ids;
+    const SplatRec* rec;
+    const float* bg;          // [V][3]
+    float* out_color;         // [V][3][H][W]
+    float* out_depth;         // [V][H][W]
+    float* out_alpha;         // [V][H][W]
+    float* final_T;           // [V][H][W]
+    uint32_t* n_contrib;      // [V][H][W]
+};
+
+struct RenderBwdArgs {
+    int P, W, H, gx, gy, T;
+    const uint32_t* tile_count;
+    const uint32_t* tile_offset;
+    const unsigned long long* view_base;
+    const uint32_t* ids;
+    const SplatRec* rec;
+    const float* bg;
+    const float* final_T;
+    const uint32_t* n_contrib;
+    const float* dL_dcolor;   // [V][3][H][W]
+    const float* dL_ddepth;   // [V][H][W] or null
+    const float* dL_dalpha;   // [V][H][W] or null
+    GradRec* acc;             // [V][P]
+};
+
+struct PreBwdArgs {
+    int P, K, deg, W, H, V, accumulate;
+    float scale_modifier;
+    const float *means3D, *shs, *colors, *scales, *rots, *cov3d;
+    const float *view, *proj, *campos, *tanfov;
+    const SplatRec* rec;
+    const GradRec* acc;
+    float *dL_dmeans2D, *dL_dmeans3D, *dL_dopac, *dL_dsh, *dL_dcolors, *dL_dscales, *dL_drots, *dL_dcov3D;
+};
+
+__global__ void ggs_k_preprocess(PreArgs a);
+__global__ void ggs_k_scan_tiles(ScanArgs a);
+__global__ void ggs_k_scatter(ScatterArgs a);
+__global__ void ggs_k_sort_tiles(SortArgs a);
+__global__ void ggs_k_render_fwd(RenderArgs a);
+__global__ void ggs_k_render_bwd(RenderBwdArgs a);
+__global__ void ggs_k_render_bwd_da(RenderBwdArgs a);
+__global__ void ggs_k_preprocess_bwd(PreBwdArgs a);

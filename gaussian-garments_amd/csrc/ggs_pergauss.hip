@@ -1,0 +1,376 @@
+// ggs_pergauss.hip -- one-lane-per-Gaussian kernels: forward preprocess (+ tile
+// histogram), key scatter, and the backward of the per-Gaussian stage.
+//
+// Roofline: HBM.  Algorithmic bytes per (view, Gaussian): forward reads 44+12K
+// (xyz 12, scale 12, rot 16, opacity 4, SH 12K), writes 48 (SplatRec) + 4 (radii);
+// backward reads 44+12K + 48 (SplatRec) + 48 (GradRec), writes 56+12K.
+// Parameters are shared by the V views of a launch and stay L2/MALL resident.
+//
+// The whole library is compiled with -ffp-contract=off; this file relies on it so
+// that radii / tile rectangles / sort keys are bit-identical to oracle/splat_oracle.c.
+#include "ggs_kernels.h"
+
+namespace {
+
+template <int DEG>
+__device__ __forceinline__ void sh_to_rgb(const float* __restrict__ sh, const float* dir, float* rgb,
+                                          unsigned& clamped) {
+    float bas[(DEG + 1) * (DEG + 1)];
+    ggs_sh_basis<DEG>(dir, bas);
+    clamped = 0;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        float r = 0.f;
+#pragma unroll
+        for (int k = 0; k < (DEG + 1) * (DEG + 1); ++k) r = r + bas[k] * sh[k * 3 + ch];
+        r = r + 0.5f;
+        if (r < 0.f) { clamped |= 1u << ch; r = 0.f; }
+        rgb[ch] = r;
+    }
+}
+
+}  // namespace
+
+// K1: grid (ceil(P/256), V).  Writes SplatRec + radii, and counts tiles per splat into
+// tile_count[v][t] (cleared by the caller's memset).
+__global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    if (g >= a.P) return;
+    const float* __restrict__ view = a.view + 16 * v;
+    const float* __restrict__ proj = a.proj + 16 * v;
+    const float tanfovx = a.tanfov[2 * v], tanfovy = a.tanfov[2 * v + 1];
+    const size_t vg = (size_t)v * a.P + g;
+    SplatRec* rec = a.rec + vg;
+    const int gx = a.gx, gy = a.gy;
+
+    int radius = 0;
+    SplatRec out;
+    out.px = out.py = out.cx = out.cy = out.cz = out.opacity = out.r = out.g = out.b = out.depth = 0.f;
+    out.clamped = 0;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+
+    const float m[3] = {a.means3D[3 * (size_t)g], a.means3D[3 * (size_t)g + 1], a.means3D[3 * (size_t)g + 2]};
+    const float pvz = view[2] * m[0] + view[6] * m[1] + view[10] * m[2] + view[14];
+    if (pvz > GGS_NEAR_Z) {
+        float hx = proj[0] * m[0] + proj[4] * m[1] + proj[8] * m[2] + proj[12];
+        float hy = proj[1] * m[0] + proj[5] * m[1] + proj[9] * m[2] + proj[13];
+        float hw = proj[3] * m[0] + proj[7] * m[1] + proj[11] * m[2] + proj[15];
+        float pw = 1.0f / (hw + GGS_W_EPS);
+        float ndx = hx * pw, ndy = hy * pw;
+        float c6[6];
+        if (a.cov3d) {
+#pragma unroll
+            for (int k = 0; k < 6; ++k) c6[k] = a.cov3d[6 * (size_t)g + k];
+        } else {
+            const float sc[3] = {a.scales[3 * (size_t)g], a.scales[3 * (size_t)g + 1], a.scales[3 * (size_t)g + 2]};
+            const float4 q4 = reinterpret_cast<const float4*>(a.rots)[g];
+            const float q[4] = {q4.x, q4.y, q4.z, q4.w};
+            ggs_cov3d(sc, a.scale_modifier, q, c6);
+        }
+        Ewa e;
+        ggs_ewa(view, m, tanfovx, tanfovy, a.W, a.H, e);
+        float s0[3], s1[3];
+        ggs_sym6_mul(c6, e.M, s0);
+        ggs_sym6_mul(c6, e.M + 3, s1);
+        float ca = (e.M[0] * s0[0] + e.M[1] * s0[1] + e.M[2] * s0[2]) + GGS_LOWPASS;
+        float cb = e.M[0] * s1[0] + e.M[1] * s1[1] + e.M[2] * s1[2];
+        float cc = (e.M[3] * s1[0] + e.M[4] * s1[1] + e.M[5] * s1[2]) + GGS_LOWPASS;
+        float det = ca * cc - cb * cb;
+        if (det != 0.0f) {
+            float det_inv = 1.f / det;
+            float mid = 0.5f * (ca + cc);
+            float root = sqrtf(ggs_max(GGS_LAMBDA_FLOOR, mid * mid - det));
+            float l1 = mid + root, l2 = mid - root;
+            float rad = ceilf(3.f * sqrtf(ggs_max(l1, l2)));
+            float px = ((ndx + 1.0f) * (float)a.W - 1.0f) * 0.5f;
+            float py = ((ndy + 1.0f) * (float)a.H - 1.0f) * 0.5f;
+            ggs_tile_rect(px, py, rad, gx, gy, x0, y0, x1, y1);
+            if ((x1 - x0) * (y1 - y0) != 0) {
+                radius = (int)rad;
+                out.px = px; out.py = py;
+                out.cx = cc * det_inv; out.cy = -cb * det_inv; out.cz = ca * det_inv;
+                out.opacity = a.opacities[g];
+                out.depth = pvz;
+                if (a.colors) {
+                    out.r = a.colors[3 * (size_t)g]; out.g = a.colors[3 * (size_t)g + 1]; out.b = a.colors[3 * (size_t)g + 2];
+                } else {
+                    const float* campos = a.campos + 3 * v;
+                    float d[3] = {m[0] - campos[0], m[1] - campos[1], m[2] - campos[2]};
+                    float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+                    d[0] = d[0] / len; d[1] = d[1] / len; d[2] = d[2] / len;
+                    const float* sh = a.shs + (size_t)g * a.K * 3;
+                    float rgb[3];
+                    switch (a.deg) {
+                        case 0: sh_to_rgb<0>(sh, d, rgb, out.clamped); break;
+                        case 1: sh_to_rgb<1>(sh, d, rgb, out.clamped); break;
+                        case 2: sh_to_rgb<2>(sh, d, rgb, out.clamped); break;
+                        default: sh_to_rgb<3>(sh, d, rgb, out.clamped); break;
+                    }
+                    out.r = rgb[0]; out.g = rgb[1]; out.b = rgb[2];
+                }
+            }
+        }
+    }
+    out.radius = radius;
+    a.radii[vg] = radius;
+    float4* dst = reinterpret_cast<float4*>(rec);
+    const float4* src = reinterpret_cast<const float4*>(&out);
+    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    if (radius > 0) {
+        uint32_t* cnt = a.tile_count + (size_t)v * a.T;
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) atomicAdd(&cnt[y * gx + x], 1u);
+    }
+}
+
+// K3: grid (ceil(P/256), V).  For every (splat, tile) instance take a slot in the tile's
+// segment and write the 64-bit key (depth bits << 32 | id).  Slot order is arbitrary;
+// the per-tile sort makes the final order (depth, id) deterministic.
+__global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
+    if (a.header->overflow) return;
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    const int v = blockIdx.y;
+    if (g >= a.P) return;
+    const SplatRec* rec = a.rec + (size_t)v * a.P + g;
+    const float4 r0 = reinterpret_cast<const float4*>(rec)[0];
+    const float4 r2 = reinterpret_cast<const float4*>(rec)[2];
+    const int radius = __float_as_int(r2.z);
+    if (radius <= 0) return;
+    int x0, y0, x1, y1;
+    ggs_tile_rect(r0.x, r0.y, (float)radius, a.gx, a.gy, x0, y0, x1, y1);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(r2.y) << 32) | (unsigned)g;
+    uint32_t* cur = a.tile_cursor + (size_t)v * a.T;
+    const uint32_t* off = a.tile_offset + (size_t)v * a.T;
+    unsigned long long* keys = a.keys + a.view_base[v];
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            const int t = y * a.gx + x;
+            const uint32_t slot = atomicAdd(&cur[t], 1u);
+            keys[(size_t)off[t] + slot] = key;
+        }
+}
+
+namespace {
+
+template <int DEG>
+__device__ __forceinline__ void sh_backward(const float* __restrict__ sh, float* __restrict__ dsh, bool accumulate,
+                                            const float* d, float len, const float* g_rgb, float* dmean) {
+    constexpr int NK = (DEG + 1) * (DEG + 1);
+    float bas[NK];
+    ggs_sh_basis<DEG>(d, bas);
+    // sum_c sh[k][c] * g[c] per coefficient -> direction gradient through d(basis)/d(dir)
+    float sg[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) {
+        float acc = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float gch = g_rgb[ch];
+            const float val = bas[k] * gch;
+            if (accumulate) dsh[k * 3 + ch] += val; else dsh[k * 3 + ch] = val;
+            acc += sh[k * 3 + ch] * gch;
+        }
+        sg[k] = acc;
+    }
+    float dd[3] = {0.f, 0.f, 0.f};
+    if constexpr (DEG > 0) {
+        const float x = d[0], y = d[1], z = d[2];
+        dd[1] += -GGS_SH_C1 * sg[1]; dd[2] += GGS_SH_C1 * sg[2]; dd[0] += -GGS_SH_C1 * sg[3];
+        if constexpr (DEG > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z;
+            const float c0 = 1.0925484305920792f, c2 = 0.31539156525252005f, c4 = 0.5462742152960396f;
+            dd[0] += c0 * y * sg[4];               dd[1] += c0 * x * sg[4];
+            dd[1] += -c0 * z * sg[5];              dd[2] += -c0 * y * sg[5];
+            dd[0] += c2 * -2.f * x * sg[6];        dd[1] += c2 * -2.f * y * sg[6];   dd[2] += c2 * 4.f * z * sg[6];
+            dd[0] += -c0 * z * sg[7];              dd[2] += -c0 * x * sg[7];
+            dd[0] += c4 * 2.f * x * sg[8];         dd[1] += c4 * -2.f * y * sg[8];
+            if constexpr (DEG > 2) {
+                const float k0 = -0.5900435899266435f, k1 = 2.890611442640554f, k2 = -0.4570457994644658f;
+                const float k3 = 0.3731763325901154f, k5 = 1.445305721320277f;
+                dd[0] += k0 * 6.f * x * y * sg[9];            dd[1] += k0 * (3.f * xx - 3.f * yy) * sg[9];
+                dd[0] += k1 * y * z * sg[10];                 dd[1] += k1 * x * z * sg[10];    dd[2] += k1 * x * y * sg[10];
+                dd[0] += k2 * -2.f * x * y * sg[11];          dd[1] += k2 * (4.f * zz - xx - 3.f * yy) * sg[11];
+                dd[2] += k2 * 8.f * y * z * sg[11];
+                dd[0] += k3 * -6.f * x * z * sg[12];          dd[1] += k3 * -6.f * y * z * sg[12];
+                dd[2] += k3 * (6.f * zz - 3.f * xx - 3.f * yy) * sg[12];
+                dd[0] += k2 * (4.f * zz - 3.f * xx - yy) * sg[13]; dd[1] += k2 * -2.f * x * y * sg[13];
+                dd[2] += k2 * 8.f * x * z * sg[13];
+                dd[0] += k5 * 2.f * x * z * sg[14];           dd[1] += k5 * -2.f * y * z * sg[14];
+                dd[2] += k5 * (xx - yy) * sg[14];
+                dd[0] += k0 * (3.f * xx - 3.f * yy) * sg[15]; dd[1] += k0 * -6.f * x * y * sg[15];
+            }
+        }
+    }
+    const float dot = d[0] * dd[0] + d[1] * dd[1] + d[2] * dd[2];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dmean[j] += (dd[j] - d[j] * dot) / len;
+}
+
+}  // namespace
+
+// K6: grid ceil(P/256).  One lane per Gaussian loops over the V views, so the sums over
+// views need no atomics and are deterministic.
+__global__ __launch_bounds__(256) void ggs_k_preprocess_bwd(PreBwdArgs a) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= a.P) return;
+    const float m[3] = {a.means3D[3 * (size_t)g], a.means3D[3 * (size_t)g + 1], a.means3D[3 * (size_t)g + 2]};
+    float c6[6], sc[3] = {0.f, 0.f, 0.f}, q[4] = {1.f, 0.f, 0.f, 0.f};
+    if (a.cov3d) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) c6[k] = a.cov3d[6 * (size_t)g + k];
+    } else {
+        sc[0] = a.scales[3 * (size_t)g]; sc[1] = a.scales[3 * (size_t)g + 1]; sc[2] = a.scales[3 * (size_t)g + 2];
+        const float4 q4 = reinterpret_cast<const float4*>(a.rots)[g];
+        q[0] = q4.x; q[1] = q4.y; q[2] = q4.z; q[3] = q4.w;
+        ggs_cov3d(sc, a.scale_modifier, q, c6);
+    }
+    float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
+    bool sh_written = a.accumulate != 0;
+    float* dsh = a.dL_dsh ? a.dL_dsh + (size_t)g * a.K * 3 : nullptr;
+
+    for (int v = 0; v < a.V; ++v) {
+        const size_t vg = (size_t)v * a.P + g;
+        const float4* rp = reinterpret_cast<const float4*>(a.rec + vg);
+        const float4 r2 = rp[2];
+        const int radius = __float_as_int(r2.z);
+        float* o2 = a.dL_dmeans2D ? a.dL_dmeans2D + 3 * vg : nullptr;
+        if (radius <= 0) {
+            if (o2) { o2[0] = 0.f; o2[1] = 0.f; o2[2] = 0.f; }
+            continue;
+        }
+        const float4* gp = reinterpret_cast<const float4*>(a.acc + vg);
+        const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];   // mx my cx cy | cz op r g | b depth - -
+        const float* __restrict__ view = a.view + 16 * v;
+        const float* __restrict__ proj = a.proj + 16 * v;
+        const float tanfovx = a.tanfov[2 * v], tanfovy = a.tanfov[2 * v + 1];
+
+        // conic -> cov2D -> (Sigma, t)
+        Ewa e;
+        ggs_ewa(view, m, tanfovx, tanfovy, a.W, a.H, e);
+        float s0[3], s1[3];
+        ggs_sym6_mul(c6, e.M, s0);
+        ggs_sym6_mul(c6, e.M + 3, s1);
+        const float ca = (e.M[0] * s0[0] + e.M[1] * s0[1] + e.M[2] * s0[2]) + GGS_LOWPASS;
+        const float cb = e.M[0] * s1[0] + e.M[1] * s1[1] + e.M[2] * s1[2];
+        const float cc = (e.M[3] * s1[0] + e.M[4] * s1[1] + e.M[5] * s1[2]) + GGS_LOWPASS;
+        const float det = ca * cc - cb * cb;
+        const float d2i = 1.f / (det * det + GGS_DET_EPS);
+        const float q0 = g0.z, q1 = g0.w, q2 = g1.x;
+        const float da = d2i * (-cc * cc * q0 + cb * cc * q1 - cb * cb * q2);
+        const float dc = d2i * (-cb * cb * q0 + ca * cb * q1 - ca * ca * q2);
+        const float db = d2i * (2.f * cb * cc * q0 - (det + 2.f * cb * cb) * q1 + 2.f * ca * cb * q2);
+        const float* M0 = e.M;
+        const float* M1 = e.M + 3;
+        dcov[0] += M0[0] * M0[0] * da + M0[0] * M1[0] * db + M1[0] * M1[0] * dc;
+        dcov[3] += M0[1] * M0[1] * da + M0[1] * M1[1] * db + M1[1] * M1[1] * dc;
+        dcov[5] += M0[2] * M0[2] * da + M0[2] * M1[2] * db + M1[2] * M1[2] * dc;
+        dcov[1] += 2.f * M0[0] * M0[1] * da + (M0[0] * M1[1] + M0[1] * M1[0]) * db + 2.f * M1[0] * M1[1] * dc;
+        dcov[2] += 2.f * M0[0] * M0[2] * da + (M0[0] * M1[2] + M0[2] * M1[0]) * db + 2.f * M1[0] * M1[2] * dc;
+        dcov[4] += 2.f * M0[1] * M0[2] * da + (M0[1] * M1[2] + M0[2] * M1[1]) * db + 2.f * M1[1] * M1[2] * dc;
+        float dJ00 = 0.f, dJ02 = 0.f, dJ11 = 0.f, dJ12 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float dM0 = 2.f * da * s0[j] + db * s1[j];
+            const float dM1 = db * s0[j] + 2.f * dc * s1[j];
+            dJ00 += dM0 * view[4 * j + 0]; dJ02 += dM0 * view[4 * j + 2];
+            dJ11 += dM1 * view[4 * j + 1]; dJ12 += dM1 * view[4 * j + 2];
+        }
+        const float tz = 1.f / e.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+        const float dtx = e.xmul * -e.fx * tz2 * dJ02;
+        const float dty = e.ymul * -e.fy * tz2 * dJ12;
+        float dtz = -e.fx * tz2 * dJ00 - e.fy * tz2 * dJ11 + 2.f * e.fx * e.tx * tz3 * dJ02 + 2.f * e.fy * e.ty * tz3 * dJ12;
+        dtz += g2.y;  // depth = t.z
+        dmean[0] += view[0] * dtx + view[1] * dty + view[2] * dtz;
+        dmean[1] += view[4] * dtx + view[5] * dty + view[6] * dtz;
+        dmean[2] += view[8] * dtx + view[9] * dty + view[10] * dtz;
+
+        // pixel mean -> NDC -> mean3D
+        const float gnx = g0.x * 0.5f * (float)a.W, gny = g0.y * 0.5f * (float)a.H;
+        if (o2) { o2[0] = gnx; o2[1] = gny; o2[2] = 0.f; }
+        const float hx = proj[0] * m[0] + proj[4] * m[1] + proj[8] * m[2] + proj[12];
+        const float hy = proj[1] * m[0] + proj[5] * m[1] + proj[9] * m[2] + proj[13];
+        const float hw = proj[3] * m[0] + proj[7] * m[1] + proj[11] * m[2] + proj[15];
+        const float pw = 1.0f / (hw + GGS_W_EPS);
+        const float mul1 = hx * pw * pw, mul2 = hy * pw * pw;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            dmean[j] += (proj[4 * j] * pw - proj[4 * j + 3] * mul1) * gnx + (proj[4 * j + 1] * pw - proj[4 * j + 3] * mul2) * gny;
+
+        dop += g1.y;
+        const float grgb[3] = {g1.z, g1.w, g2.x};
+        if (a.colors) {
+            dcol[0] += grgb[0]; dcol[1] += grgb[1]; dcol[2] += grgb[2];
+        } else if (dsh) {
+            const unsigned clamped = __float_as_uint(r2.w);
+            const float gsh[3] = {(clamped & 1u) ? 0.f : grgb[0], (clamped & 2u) ? 0.f : grgb[1], (clamped & 4u) ? 0.f : grgb[2]};
+            const float* campos = a.campos + 3 * v;
+            float d[3] = {m[0] - campos[0], m[1] - campos[1], m[2] - campos[2]};
+            const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+            d[0] = d[0] / len; d[1] = d[1] / len; d[2] = d[2] / len;
+            const float* sh = a.shs + (size_t)g * a.K * 3;
+            switch (a.deg) {
+                case 0: sh_backward<0>(sh, dsh, sh_written, d, len, gsh, dmean); break;
+                case 1: sh_backward<1>(sh, dsh, sh_written, d, len, gsh, dmean); break;
+                case 2: sh_backward<2>(sh, dsh, sh_written, d, len, gsh, dmean); break;
+                default: sh_backward<3>(sh, dsh, sh_written, d, len, gsh, dmean); break;
+            }
+            sh_written = true;
+        }
+    }
+
+    const bool acc = a.accumulate != 0;
+    if (dsh && !a.colors) {
+        const int nk = (a.deg + 1) * (a.deg + 1);
+        // coefficients above the active degree (and everything if no view saw the splat) get zero
+        for (int k = sh_written ? nk : 0; k < a.K; ++k)
+            if (!acc) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
+    }
+    auto put = [acc](float* p, float v) { if (acc) *p += v; else *p = v; };
+    put(a.dL_dmeans3D + 3 * (size_t)g, dmean[0]); put(a.dL_dmeans3D + 3 * (size_t)g + 1, dmean[1]);
+    put(a.dL_dmeans3D + 3 * (size_t)g + 2, dmean[2]);
+    put(a.dL_dopac + g, dop);
+    if (a.colors && a.dL_dcolors) {
+        put(a.dL_dcolors + 3 * (size_t)g, dcol[0]); put(a.dL_dcolors + 3 * (size_t)g + 1, dcol[1]);
+        put(a.dL_dcolors + 3 * (size_t)g + 2, dcol[2]);
+    }
+    if (a.cov3d) {
+        if (a.dL_dcov3D)
+#pragma unroll
+            for (int k = 0; k < 6; ++k) put(a.dL_dcov3D + 6 * (size_t)g + k, dcov[k]);
+    } else if (a.dL_dscales && a.dL_drots) {
+        // Sigma = M^T M, M[k][j] = s_k R[j][k]  ->  dM = 2 M Gs, ds_k = sum_j dM[k][j] R[j][k], dR[j][k] = s_k dM[k][j]
+        float R[9], Mm[9], sv[3];
+        ggs_quat_R(q, R);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            sv[k] = a.scale_modifier * sc[k];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) Mm[k * 3 + j] = sv[k] * R[j * 3 + k];
+        }
+        const float Gs[9] = {dcov[0], 0.5f * dcov[1], 0.5f * dcov[2], 0.5f * dcov[1], dcov[3],
+                             0.5f * dcov[4], 0.5f * dcov[2], 0.5f * dcov[4], dcov[5]};
+        float dR[9], ds[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            float accs = 0.f;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const float dM = 2.f * (Mm[k * 3] * Gs[j] + Mm[k * 3 + 1] * Gs[3 + j] + Mm[k * 3 + 2] * Gs[6 + j]);
+                accs += dM * R[j * 3 + k];
+                dR[j * 3 + k] = sv[k] * dM;
+            }
+            ds[k] = a.scale_modifier * accs;
+        }
+        const float r = q[0], x = q[1], y = q[2], z = q[3];
+        const float dq0 = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);
+        const float dq1 = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
+        const float dq2 = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
+        const float dq3 = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
+        put(a.dL_dscales + 3 * (size_t)g, ds[0]); put(a.dL_dscales + 3 * (size_t)g + 1, ds[1]);
+        put(a.dL_dscales + 3 * (size_t)g + 2, ds[2]);
+        put(a.dL_drots + 4 * (size_t)g, dq0); put(a.dL_drots + 4 * (size_t)g + 1, dq1);
+        put(a.dL_drots + 4 * (size_t)g + 2, dq2); put(a.dL_drots + 4 * (size_t)g + 3, dq3);
+    }
+}

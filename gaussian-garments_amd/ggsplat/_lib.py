@@ -1,0 +1,75 @@
+"""ctypes binding of libggsplat.so (include/ggsplat.h).
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load,
+every entry point raises.  PyTorch is imported first so that the library binds to the
+HIP runtime PyTorch already loaded (same SONAME libamdhip64.so.7) -- device pointers,
+streams and the caching allocator are PyTorch's; the kernels are ours.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede the CDLL below: one HIP runtime per process)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libggsplat.so"))
+
+
+class GgsParams(C.Structure):
+    _fields_ = [("P", C.c_int), ("K", C.c_int), ("sh_degree", C.c_int), ("W", C.c_int), ("H", C.c_int),
+                ("n_views", C.c_int), ("scale_modifier", C.c_float), ("prefiltered", C.c_int), ("debug", C.c_int)]
+
+
+class GgsError(RuntimeError):
+    pass
+
+
+_lib = None
+
+_PTR = C.c_void_p
+_SIGS = {
+    "ggs_workspace_sizes": (C.c_int, [C.POINTER(GgsParams), C.c_size_t, C.POINTER(C.c_size_t),
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "ggs_bin_layout": (C.c_int, [C.POINTER(GgsParams), C.c_size_t, C.POINTER(C.c_size_t)]),
+    "ggs_backward_scratch_bytes": (C.c_size_t, [C.POINTER(GgsParams)]),
+    "ggs_forward": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 6),
+    "ggs_backward": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 13 + [C.c_size_t] + [_PTR] * 13 + [C.c_int, _PTR]),
+    "ggs_mesh_bind_forward": (C.c_int, [C.c_int, C.c_int] + [_PTR] * 11),
+    "ggs_mesh_bind_backward": (C.c_int, [C.c_int, C.c_int] + [_PTR] * 15),
+    "ggs_last_error": (C.c_char_p, []),
+    "ggs_version": (C.c_char_p, []),
+}
+EXPORTS = tuple(_SIGS)
+
+
+def lib():
+    """Load (once) and return the CDLL.  Raises GgsError if the HIP library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GgsError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "or `make -C gaussian-garments_amd/csrc`. There is no CPU fallback.")
+        try:
+            L = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover
+            raise GgsError(f"cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().ggs_last_error().decode("utf-8", "replace")
+        raise GgsError(f"{what} failed (code {rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL).  The tensor must be contiguous."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "ggsplat: tensor must be contiguous"
+    return C.c_void_p(t.data_ptr())

@@ -1,0 +1,198 @@
+"""Host side of the rasterizer: workspace management + the autograd Function.
+
+Mirrors the Python half of the reference's external extension
+(`diff_gaussian_rasterization_depth_alpha`): an autograd Function whose forward
+calls the native forward and keeps the opaque geom / binning / image buffers for
+the native backward.  Call site being served: gaussian_renderer/__init__.py:54,
+:103-111.  Differences, all MI355X-motivated:
+  * the native side is a C ABI over caller-allocated workspaces (no resize callback);
+  * one call can batch V views (grid dimension = view) over the same Gaussians;
+  * the only host sync is one 16-byte header read-back per call (num_rendered +
+    overflow flag), never per kernel.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import GgsParams, check, lib, ptr
+
+# running estimate of the binning capacity per (device, P, W, H, V); grows on overflow
+_cap_hint: Dict[Tuple, int] = {}
+
+
+def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _stream_ptr(dev) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+class ForwardState:
+    """Everything the backward needs (the reference keeps the same things in ctx)."""
+    __slots__ = ("prm", "bg", "means3D", "shs", "colors", "opac", "scales", "rots", "cov", "view", "proj",
+                 "campos", "tanfov", "geom", "bin", "cap", "img", "num_rendered")
+
+
+def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, *, view, proj, campos,
+                  tanfov, bg, W: int, H: int, sh_degree: int, scale_modifier: float = 1.0, debug: bool = False,
+                  keep_state: bool = True):
+    """Rasterize V views.  view/proj [V,16], campos [V,3], tanfov [V,2], bg [V,3] or [3].
+    Returns color [V,3,H,W], radii [V,P] int32, depth [V,H,W], alpha [V,H,W], state."""
+    L = lib()
+    dev = means3D.device
+    if dev.type != "cuda":
+        raise _lib.GgsError("ggsplat: tensors must live on the GPU (there is no CPU path in the product)")
+    means3D, opacities, shs, colors_precomp = _f32c(means3D), _f32c(opacities), _f32c(shs), _f32c(colors_precomp)
+    scales, rotations, cov3D_precomp = _f32c(scales), _f32c(rotations), _f32c(cov3D_precomp)
+    if shs is not None and shs.numel() == 0:
+        shs = None
+    if colors_precomp is not None and colors_precomp.numel() == 0:
+        colors_precomp = None
+    if scales is not None and scales.numel() == 0:
+        scales = None
+    if rotations is not None and rotations.numel() == 0:
+        rotations = None
+    if cov3D_precomp is not None and cov3D_precomp.numel() == 0:
+        cov3D_precomp = None
+    view = _f32c(view).reshape(-1, 16)
+    V = view.shape[0]
+    proj = _f32c(proj).reshape(V, 16)
+    campos = _f32c(campos).reshape(V, 3)
+    tanfov = _f32c(tanfov).reshape(V, 2)
+    bg = _f32c(bg).to(dev)
+    bg = bg.reshape(1, 3).expand(V, 3).contiguous() if bg.numel() == 3 else bg.reshape(V, 3).contiguous()
+    P = means3D.shape[0]
+    K = shs.shape[1] if shs is not None else 0
+    prm = GgsParams(P, K, int(sh_degree), int(W), int(H), V, float(scale_modifier), 0, int(bool(debug)))
+
+    color = torch.empty(V, 3, H, W, device=dev, dtype=torch.float32)
+    depth = torch.empty(V, H, W, device=dev, dtype=torch.float32)
+    alpha = torch.empty(V, H, W, device=dev, dtype=torch.float32)
+    radii = torch.empty(V, P, device=dev, dtype=torch.int32)
+
+    key = (dev.index, P, W, H, V)
+    cap = _cap_hint.get(key, max(8 * P * V, 1 << 16))
+    stream = _stream_ptr(dev)
+    host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+    while True:
+        gsz, isz, bsz = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        check(L.ggs_workspace_sizes(C.byref(prm), cap, C.byref(gsz), C.byref(isz), C.byref(bsz)), "ggs_workspace_sizes")
+        geom = torch.empty(gsz.value, device=dev, dtype=torch.uint8)
+        img = torch.empty(isz.value, device=dev, dtype=torch.uint8)
+        binb = torch.empty(bsz.value, device=dev, dtype=torch.uint8)
+        check(L.ggs_forward(C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities),
+                            ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos),
+                            ptr(tanfov), ptr(geom), ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha),
+                            ptr(radii), stream), "ggs_forward")
+        host.copy_(binb[:16].view(torch.int64), non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        n, overflow = int(host[0]), int(host[1])
+        if not overflow:
+            _cap_hint[key] = max(cap, 1 << 16) if n * 2 <= cap else int(n * 2)
+            break
+        cap = int(n * 1.5) + 1024          # n is exact even when the segment was too small
+        _cap_hint[key] = cap
+    st = None
+    if keep_state:
+        st = ForwardState()
+        st.prm, st.bg, st.means3D, st.shs, st.colors, st.opac = prm, bg, means3D, shs, colors_precomp, opacities
+        st.scales, st.rots, st.cov, st.view, st.proj, st.campos, st.tanfov = scales, rotations, cov3D_precomp, view, proj, campos, tanfov
+        st.geom, st.bin, st.cap, st.img, st.num_rendered = geom, binb, cap, img, n
+    return color, radii, depth, alpha, st
+
+
+def backward_views(st: ForwardState, dL_dcolor, dL_ddepth=None, dL_dalpha=None, want_means2D: bool = True,
+                   out: Optional[Dict[str, torch.Tensor]] = None, accumulate: bool = False) -> Dict[str, torch.Tensor]:
+    """Gradients summed over the V views of `st` (dL_dmeans2D stays per view)."""
+    L = lib()
+    prm = st.prm
+    dev = st.means3D.device
+    P, K, V = prm.P, prm.K, prm.n_views
+    dL_dcolor = _f32c(dL_dcolor)
+    dL_ddepth, dL_dalpha = _f32c(dL_ddepth), _f32c(dL_dalpha)
+    new = (lambda *s: torch.empty(*s, device=dev, dtype=torch.float32))
+    g = out if out is not None else {}
+    if "means3D" not in g:
+        g["means3D"] = new(P, 3)
+        g["opacities"] = new(P, 1)
+        if st.shs is not None:
+            g["shs"] = new(P, K, 3)
+        else:
+            g["colors_precomp"] = new(P, 3)
+        if st.cov is not None:
+            g["cov3D_precomp"] = new(P, 6)
+        else:
+            g["scales"], g["rotations"] = new(P, 3), new(P, 4)
+        accumulate = False
+    if want_means2D and "means2D" not in g:
+        g["means2D"] = new(V, P, 3)
+    scratch = torch.empty(L.ggs_backward_scratch_bytes(C.byref(prm)), device=dev, dtype=torch.uint8)
+    check(L.ggs_backward(C.byref(prm), ptr(st.bg), ptr(st.means3D), ptr(st.shs), ptr(st.colors), ptr(st.scales),
+                         ptr(st.rots), ptr(st.cov), ptr(st.view), ptr(st.proj), ptr(st.campos), ptr(st.tanfov),
+                         ptr(st.geom), ptr(st.bin), st.cap, ptr(st.img), ptr(dL_dcolor), ptr(dL_ddepth),
+                         ptr(dL_dalpha), ptr(scratch), ptr(g.get("means2D") if want_means2D else None),
+                         ptr(g["means3D"]), ptr(g["opacities"]), ptr(g.get("shs")), ptr(g.get("colors_precomp")),
+                         ptr(g.get("scales")), ptr(g.get("rotations")), ptr(g.get("cov3D_precomp")),
+                         int(bool(accumulate)), _stream_ptr(dev)), "ggs_backward")
+    return g
+
+
+def bin_sections(st: ForwardState) -> Dict[str, torch.Tensor]:
+    """Typed views into the binning buffer of a forward (tests / debugging)."""
+    off = (C.c_size_t * 8)()
+    check(lib().ggs_bin_layout(C.byref(st.prm), st.cap, off), "ggs_bin_layout")
+    V = st.prm.n_views
+    T = ((st.prm.W + 15) // 16) * ((st.prm.H + 15) // 16)
+    b = st.bin
+
+    def sec(i, nbytes, dt):
+        return b[off[i]:off[i] + nbytes].view(dt)
+
+    return dict(header=sec(0, 16, torch.int64), tile_count=sec(1, V * T * 4, torch.int32).reshape(V, T),
+                tile_offset=sec(3, V * T * 4, torch.int32).reshape(V, T), view_base=sec(4, V * 8, torch.int64),
+                keys=sec(5, st.cap * 8, torch.int64), ids=sec(6, st.cap * 4, torch.int32))
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    """Single-view autograd op with the reference extension's argument order."""
+
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
+        dev = means3D.device
+        tanfov = torch.tensor([[settings.tanfovx, settings.tanfovy]], dtype=torch.float32, device=dev)
+        color, radii, depth, alpha, st = forward_views(
+            means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp,
+            view=settings.viewmatrix, proj=settings.projmatrix, campos=settings.campos, tanfov=tanfov,
+            bg=settings.bg, W=settings.image_width, H=settings.image_height, sh_degree=settings.sh_degree,
+            scale_modifier=settings.scale_modifier, debug=settings.debug, keep_state=True)
+        ctx.set_materialize_grads(False)      # unused depth / alpha outputs -> None, not zeros
+        ctx.st = st
+        ctx.m2d_shape = means2D.shape
+        # outputs are never saved: callers mutate them in place (utils/loss_utils.py:44-46)
+        ctx.mark_non_differentiable(radii)
+        return color[0], radii[0], depth, alpha
+
+    @staticmethod
+    def backward(ctx, g_color, g_radii, g_depth, g_alpha):
+        st = ctx.st
+        H, W = st.prm.H, st.prm.W
+        if g_color is None:
+            g_color = torch.zeros(3, H, W, device=st.means3D.device)
+        g = backward_views(st, g_color.reshape(1, 3, H, W), None if g_depth is None else g_depth.reshape(1, H, W),
+                           None if g_alpha is None else g_alpha.reshape(1, H, W), want_means2D=True)
+        return (g["means3D"], g["means2D"][0].reshape(ctx.m2d_shape), g.get("shs"), g.get("colors_precomp"),
+                g["opacities"].reshape(st.opac.shape), g.get("scales"), g.get("rotations"), g.get("cov3D_precomp"), None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                     cov3Ds_precomp, settings)

@@ -1,0 +1,152 @@
+/*
+ * ggsplat.h -- C ABI of libggsplat.so, the MI355X (gfx950) differentiable
+ * Gaussian-splat rasterizer.  This is the drop-in boundary of the hot path:
+ * exactly what the reference's FFI for this path binds.
+ *
+ * Reference interface each entry point replaces (paths relative to the
+ * reference repo eth-ait/Gaussian-Garments):
+ *
+ *   ggs_forward   <- `_C.rasterize_gaussians` of the external CUDA extension
+ *                    diff_gaussian_rasterization_depth_alpha, reached through
+ *                    GaussianRasterizer.forward at gaussian_renderer/__init__.py:54,
+ *                    :103-111 (settings built at :39-52).  Argument meaning,
+ *                    layouts and return order (color, radii, depth, alpha) follow
+ *                    that call site.
+ *   ggs_backward  <- `_C.rasterize_gaussians_backward`, reached implicitly through
+ *                    loss.backward() at s2_registration.py:306 / s3_appearance.py:141.
+ *   ggs_workspace_sizes
+ *                 <- the geomBuffer / binningBuffer / imgBuffer byte tensors the
+ *                    upstream extension grows through a resize callback; here the
+ *                    caller allocates (no callback, no host sync inside the ABI).
+ *   ggs_mesh_bind_forward / ggs_mesh_bind_backward
+ *                 <- MeshGaussianModel.update_face_coor + get_xyz / get_scaling /
+ *                    get_rotation (scene/mesh_gaussian_model.py:90-95, 105-128) with
+ *                    compute_face_orientation (utils/graphics_utils.py:118-137) and
+ *                    the AvatarGaussianModel barycentric origin
+ *                    (scene/avatar_gaussian_model.py:140-159).
+ *
+ * Conventions
+ *   - Every pointer is a DEVICE pointer owned by the caller (PyTorch); the
+ *     library never allocates, frees or retains them.  fp32 unless stated.
+ *   - `n_views` >= 1 batches V cameras over the same Gaussians in one call
+ *     (grid dimension = view).  Per-view arrays are [V][...] contiguous.
+ *     V = 1 is exactly the reference's per-camera call.
+ *   - Matrices arrive transposed and flat like the reference passes them
+ *     (scene/cameras.py:59-61): x' = m[0]x + m[4]y + m[8]z + m[12].
+ *   - Quaternions are (w,x,y,z), assumed unit.  SH layout [P][K][3].
+ *   - All work is enqueued on `stream`; nothing synchronises unless
+ *     GgsParams.debug != 0 (mirrors pipe.debug: sync + error check per kernel).
+ *   - Return value: 0 on success, negative error code otherwise; the message is
+ *     in a thread-local buffer (ggs_last_error).  No C++ exception crosses the ABI.
+ *   - Re-entrant; no global mutable state besides the thread-local error string.
+ *     One process per GPU for multi-GPU use.
+ */
+#ifndef GGSPLAT_H
+#define GGSPLAT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct GgsParams {
+    int P;                /* number of Gaussians                                            */
+    int K;                /* SH coefficients per Gaussian stored in `shs` (0 if colors given) */
+    int sh_degree;        /* active SH degree, 0..3, (sh_degree+1)^2 <= K                    */
+    int W, H;             /* image size in pixels                                           */
+    int n_views;          /* V >= 1                                                         */
+    float scale_modifier; /* GaussianRasterizationSettings.scale_modifier                   */
+    int prefiltered;      /* accepted for API parity; the reference always passes False      */
+    int debug;            /* != 0: hipStreamSynchronize + error check after every kernel     */
+} GgsParams;
+
+/* Layout of the first 16 bytes of the binning buffer: read it back (async copy)
+ * to learn num_rendered and whether `bin_capacity` was too small. */
+typedef struct GgsBinHeader {
+    unsigned long long num_rendered; /* sum over views of tiles touched (N)                   */
+    unsigned long long overflow;     /* != 0: N > bin_capacity, outputs are invalid; retry     */
+} GgsBinHeader;
+
+/* Error codes */
+#define GGS_OK 0
+#define GGS_ERR_ARG (-1)    /* bad argument combination (both/neither of shs|colors, scales+rots|cov3D, ...) */
+#define GGS_ERR_HIP (-2)    /* a HIP call or kernel launch failed                                            */
+#define GGS_ERR_SIZE (-3)   /* size does not fit the index types                                             */
+
+/* Bytes the caller must provide for the three opaque workspaces.
+ * bin_capacity = max number of (Gaussian, tile) instances over all views. */
+int ggs_workspace_sizes(const GgsParams* prm, size_t bin_capacity, size_t* geom_bytes, size_t* img_bytes,
+                        size_t* bin_bytes);
+
+/* Introspection (tests / debugging): byte offsets of the sections of the binning buffer, in order
+ * {header, tile_count [V][T] u32, tile_cursor [V][T] u32, tile_offset [V][T] u32, view_base [V] u64,
+ *  keys [cap] u64, ids [cap] u32, total}.  Not part of the reference's interface. */
+int ggs_bin_layout(const GgsParams* prm, size_t bin_capacity, size_t offsets[8]);
+
+/* Bytes of the gradient-accumulator scratch ggs_backward needs (V*P*48). */
+size_t ggs_backward_scratch_bytes(const GgsParams* prm);
+
+/*
+ * Forward.  Exactly one of shs [P][K][3] / colors_precomp [P][3] and exactly one of
+ * (scales [P][3], rotations [P][4]) / cov3D_precomp [P][6] must be non-NULL.
+ *   bg [V][3], view [V][16], proj [V][16], campos [V][3], tanfov [V][2] = (tanfovx, tanfovy)
+ *   out_color [V][3][H][W], out_depth [V][H][W], out_alpha [V][H][W], radii [V][P] int32
+ * geom / bin / img: workspaces of ggs_workspace_sizes(); they carry the state backward needs.
+ */
+int ggs_forward(const GgsParams* prm, const float* bg, const float* means3D, const float* shs,
+                const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                const float* cov3D_precomp, const float* view, const float* proj, const float* campos,
+                const float* tanfov, void* geom, void* bin, size_t bin_capacity, void* img, float* out_color,
+                float* out_depth, float* out_alpha, int* radii, void* stream);
+
+/*
+ * Backward.  dL_dcolor [V][3][H][W]; dL_ddepth / dL_dalpha [V][H][W] or NULL (zero).
+ * geom / bin / img / bin_capacity: exactly what the matching ggs_forward call was given.
+ * scratch: ggs_backward_scratch_bytes() bytes.
+ * Outputs (summed over the V views; overwritten unless accumulate != 0):
+ *   dL_dmeans3D [P][3], dL_dopacities [P], and by input mode
+ *   dL_dshs [P][K][3] | dL_dcolors [P][3];  (dL_dscales [P][3], dL_drotations [P][4]) | dL_dcov3D [P][6].
+ *   Pointers of the unused mode may be NULL.
+ * dL_dmeans2D [V][P][3] (per view, never summed; may be NULL): gradient w.r.t. the NDC xy of the
+ *   projected mean (pixel gradient * 0.5W / 0.5H), z = 0 -- what lands in render()'s
+ *   screenspace_points.grad (gaussian_renderer/__init__.py:29-33).
+ */
+int ggs_backward(const GgsParams* prm, const float* bg, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* scales, const float* rotations,
+                 const float* cov3D_precomp, const float* view, const float* proj, const float* campos,
+                 const float* tanfov, const void* geom, const void* bin, size_t bin_capacity,
+                 const void* img, const float* dL_dcolor, const float* dL_ddepth, const float* dL_dalpha, void* scratch,
+                 float* dL_dmeans2D, float* dL_dmeans3D, float* dL_dopacities, float* dL_dshs, float* dL_dcolors,
+                 float* dL_dscales, float* dL_drotations, float* dL_dcov3D, int accumulate, void* stream);
+
+/*
+ * Mesh binding (local Gaussian frame -> world), forward and backward.
+ *   verts [V_m][3], faces [F][3] int64, binding [P] int64 (face of each Gaussian)
+ *   local_xyz [P][3], log_scaling [P][3] (pre-exp), raw_rot [P][4] (pre-normalise, wxyz)
+ *   bary [P][3] or NULL: barycentric origin (AvatarGaussianModel); NULL = face centre.
+ * Outputs: xyz [P][3], scaling [P][3], rotation [P][4] (unit, wxyz).
+ * Backward adds into dL_dverts [V_m][3] (atomics; caller zeroes) and overwrites
+ * dL_dlocal_xyz / dL_dlog_scaling / dL_draw_rot.
+ */
+int ggs_mesh_bind_forward(int P, int F, const float* verts, const int64_t* faces, const int64_t* binding,
+                          const float* local_xyz, const float* log_scaling, const float* raw_rot,
+                          const float* bary, float* xyz, float* scaling, float* rotation, void* stream);
+
+int ggs_mesh_bind_backward(int P, int F, const float* verts, const int64_t* faces, const int64_t* binding,
+                           const float* local_xyz, const float* log_scaling, const float* raw_rot,
+                           const float* bary, const float* dL_dxyz, const float* dL_dscaling,
+                           const float* dL_drotation, float* dL_dverts, float* dL_dlocal_xyz,
+                           float* dL_dlog_scaling, float* dL_draw_rot, void* stream);
+
+/* Thread-local message of the last failing call on this thread ("" if none). */
+const char* ggs_last_error(void);
+
+/* Library version / build target string, e.g. "ggsplat 0.1 gfx950". */
+const char* ggs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGSPLAT_H */

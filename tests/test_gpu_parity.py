@@ -1,0 +1,218 @@
+"""GPU parity: HIP path (through the C ABI, via the drop-in module) vs the C oracle.
+
+Bars (north_star): bit-exact for integer / index outputs (radii, num_rendered, per-pixel
+contributor counts, per-tile sorted id lists); <= 1e-4 relative L1 for fp32 images and
+gradients (tolerance REL_L1_TOL in helpers.py).
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import REL_L1_TOL, cam_kwargs, rel_l1, seeded_image_weights, small_scene
+from oracle.c_oracle import COracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _settings(cam, bg, sh_degree, dev, scale_modifier=1.0, debug=False):
+    from diff_gaussian_rasterization_depth_alpha import GaussianRasterizationSettings
+    return GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
+        tanfovy=math.tan(cam.FoVy * 0.5), bg=torch.as_tensor(bg, dtype=torch.float32, device=dev),
+        scale_modifier=scale_modifier, viewmatrix=cam.world_view_transform.to(dev),
+        projmatrix=cam.full_proj_transform.to(dev), sh_degree=sh_degree, campos=cam.camera_center.to(dev),
+        prefiltered=False, debug=debug)
+
+
+def _run_hip(sc, cam, bg, mode, weights, dev="cuda", scale_modifier=1.0):
+    from diff_gaussian_rasterization_depth_alpha import GaussianRasterizer
+    from oracle import torch_oracle as TO
+    leaf = {}
+
+    def L(name, t):
+        leaf[name] = t.clone().to(dev).requires_grad_(True)
+        return leaf[name]
+
+    P = sc["means3D"].shape[0]
+    kw = dict(means3D=L("means3D", sc["means3D"]), means2D=L("means2D", torch.zeros(P, 3)),
+              opacities=L("opacities", sc["opacities"]))
+    if mode["sh"]:
+        kw["shs"] = L("shs", sc["shs"])
+    else:
+        kw["colors_precomp"] = L("colors_precomp", sc["colors"])
+    if mode["cov"]:
+        kw["cov3D_precomp"] = L("cov3D_precomp", sc["cov"])
+    else:
+        kw["scales"] = L("scales", sc["scales"])
+        kw["rotations"] = L("rotations", sc["rotations"])
+    rast = GaussianRasterizer(_settings(cam, bg, sc["sh_degree"], dev, scale_modifier))
+    color, radii, depth, alpha = rast(**kw)
+    wc, wd, wa = (w.to(dev) for w in weights)
+    loss = (color * wc).sum()
+    if mode.get("da", True):
+        loss = loss + (depth * wd).sum() + (alpha * wa).sum()
+    loss.backward()
+    grads = {k: v.grad.detach().cpu() for k, v in leaf.items() if v.grad is not None}
+    return color.detach().cpu(), radii.cpu(), depth.detach().cpu(), alpha.detach().cpu(), grads
+
+
+def _run_oracle(sc, cam, bg, mode, weights, scale_modifier=1.0):
+    kw = cam_kwargs(cam, bg)
+    co = COracle(means3D=sc["means3D"], opacities=sc["opacities"], shs=sc["shs"] if mode["sh"] else None,
+                 colors_precomp=None if mode["sh"] else sc["colors"],
+                 scales=None if mode["cov"] else sc["scales"], rotations=None if mode["cov"] else sc["rotations"],
+                 cov3D_precomp=sc["cov"] if mode["cov"] else None, sh_degree=sc["sh_degree"],
+                 scale_modifier=scale_modifier, **kw)
+    wc, wd, wa = weights
+    g = co.backward(wc, wd if mode.get("da", True) else None, wa if mode.get("da", True) else None)
+    return co, g
+
+
+def _add_precomp(sc):
+    from oracle import torch_oracle as TO
+    g = torch.Generator().manual_seed(99)
+    sc["cov"] = TO.cov3d_from_scale_rot(sc["scales"], 1.0, sc["rotations"]).contiguous()
+    sc["colors"] = torch.rand(sc["means3D"].shape[0], 3, generator=g)
+    return sc
+
+
+def _compare(sc, cam, bg, mode, scale_modifier=1.0):
+    weights = seeded_image_weights(cam.image_width, cam.image_height)
+    color, radii, depth, alpha, grads = _run_hip(sc, cam, bg, mode, weights, scale_modifier=scale_modifier)
+    co, og = _run_oracle(sc, cam, bg, mode, weights, scale_modifier=scale_modifier)
+    assert np.array_equal(radii.numpy(), co.radii), "radii must be bit-exact"
+    assert rel_l1(color, co.color) <= REL_L1_TOL
+    assert rel_l1(depth, co.depth) <= REL_L1_TOL
+    assert rel_l1(alpha, co.alpha) <= REL_L1_TOL
+    names = {"means3D": "means3D", "means2D": "means2D", "opacities": "opacities", "shs": "shs",
+             "colors_precomp": "colors", "cov3D_precomp": "cov3D", "scales": "scales", "rotations": "rotations"}
+    for k, t in grads.items():
+        ref = og[names[k]]
+        assert rel_l1(t.reshape(ref.shape), ref) <= REL_L1_TOL, f"grad {k}"
+    return co
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_sh_scale_rot_path(deg):
+    sc, cam = small_scene(P=700, W=96, H=80, sh_degree=deg, seed=10 + deg)
+    _compare(sc, cam, (0.2, 0.5, 0.7), dict(sh=True, cov=False))
+
+
+def test_precomp_paths_and_clamp_termination():
+    sc, cam = small_scene(P=500, W=70, H=50, sh_degree=1, seed=5, scale_mul=25.0, opacity_boost=3.0, cam_index=2)
+    sc = _add_precomp(sc)
+    co = _compare(sc, cam, (0.9, 0.1, 0.4), dict(sh=False, cov=True))
+    it = co.internals()
+    assert it["final_T"].min() < 2e-4          # early termination actually exercised
+
+
+def test_no_depth_alpha_grads_kernel():
+    sc, cam = small_scene(P=800, W=64, H=64, sh_degree=0, seed=21, scale_mul=6.0)
+    _compare(sc, cam, (0.0, 0.0, 0.0), dict(sh=True, cov=False, da=False))
+
+
+def test_scale_modifier():
+    sc, cam = small_scene(P=400, W=64, H=48, sh_degree=0, seed=23, scale_mul=5.0)
+    _compare(sc, cam, (1.0, 1.0, 1.0), dict(sh=True, cov=False), scale_modifier=0.7)
+
+
+def test_internals_bit_exact():
+    """num_rendered, per-tile sorted lists and per-pixel contributor counts are index work: exact."""
+    from ggsplat import rasterizer as R
+    from ggsplat.synthetic import stack_cameras
+    sc, cam = small_scene(P=3000, W=160, H=120, sh_degree=0, seed=31, scale_mul=5.0)
+    dev = "cuda"
+    cams = stack_cameras([cam], device=dev)
+    color, radii, depth, alpha, st = R.forward_views(
+        sc["means3D"].to(dev), sc["opacities"].to(dev), sc["shs"].to(dev), None, sc["scales"].to(dev),
+        sc["rotations"].to(dev), None, view=cams["view"], proj=cams["proj"], campos=cams["campos"],
+        tanfov=cams["tanfov"], bg=torch.zeros(3, device=dev), W=160, H=120, sh_degree=0)
+    co = COracle(means3D=sc["means3D"], opacities=sc["opacities"], shs=sc["shs"], scales=sc["scales"],
+                 rotations=sc["rotations"], sh_degree=0, **cam_kwargs(cam, (0, 0, 0)))
+    assert st.num_rendered == co.num_rendered
+    it = co.internals()
+    T = 10 * 8
+    HW = 160 * 120
+    img = st.img.cpu()
+    img_half = (img.numel() // 2)
+    final_T = img[:HW * 4].view(torch.float32).reshape(120, 160)
+    n_contrib = img[img_half:img_half + HW * 4].view(torch.int32).reshape(120, 160)
+    assert np.array_equal(n_contrib.numpy().astype(np.uint32), it["n_contrib"])
+    assert rel_l1(final_T, it["final_T"]) <= REL_L1_TOL
+    # sorted id lists, tile by tile (view_base is 0 for a single view)
+    from ggsplat.rasterizer import bin_sections
+    sec = bin_sections(st)
+    counts = sec["tile_count"].cpu().numpy().astype(np.int64).reshape(-1)
+    assert np.array_equal(np.concatenate([[0], np.cumsum(counts)]), it["tile_start"])
+    assert np.array_equal(sec["tile_offset"].cpu().numpy().astype(np.int64).reshape(-1), it["tile_start"][:-1])
+    assert np.array_equal(sec["ids"].cpu().numpy()[:co.num_rendered].astype(np.uint32), it["list"])
+    # per-Gaussian records: bit-exact geometry
+    rec = st.geom.cpu()[:3000 * 48].view(torch.float32).reshape(3000, 12).numpy()
+    vis = co.radii > 0
+    assert np.array_equal(rec[vis, 0:2], it["xy"][vis])
+    assert np.array_equal(rec[vis, 9], it["depth"][vis])
+    assert np.array_equal(rec[vis][:, [2, 3, 4, 5]], it["conic_opacity"][vis])
+    assert np.array_equal(rec[vis][:, [6, 7, 8]], it["rgb"][vis])
+
+
+def test_empty_and_offscreen():
+    """P = 0 and all-culled inputs: background image, zero alpha, no crash."""
+    from diff_gaussian_rasterization_depth_alpha import GaussianRasterizer
+    sc, cam = small_scene(P=50, W=48, H=32, sh_degree=0, seed=2)
+    dev = "cuda"
+    bg = (0.3, 0.6, 0.9)
+    rast = GaussianRasterizer(_settings(cam, bg, 0, dev))
+    behind = sc["means3D"].to(dev) * 0 + cam.camera_center.to(dev) - 5.0 * torch.tensor(cam.R[:, 2], dtype=torch.float32, device=dev)
+    color, radii, depth, alpha = rast(means3D=behind, means2D=torch.zeros(50, 3, device=dev), opacities=sc["opacities"].to(dev),
+                                      shs=sc["shs"].to(dev), scales=sc["scales"].to(dev), rotations=sc["rotations"].to(dev))
+    assert int((radii > 0).sum()) == 0
+    assert torch.allclose(color, torch.tensor(bg, device=dev)[:, None, None].expand_as(color))
+    assert float(alpha.abs().max()) == 0.0
+    e = torch.zeros(0, 3, device=dev)
+    color, radii, depth, alpha = rast(means3D=e, means2D=e, opacities=torch.zeros(0, 1, device=dev),
+                                      shs=torch.zeros(0, 1, 3, device=dev), scales=e, rotations=torch.zeros(0, 4, device=dev))
+    assert radii.numel() == 0 and torch.allclose(color, torch.tensor(bg, device=dev)[:, None, None].expand_as(color))
+
+
+def test_argument_errors():
+    from diff_gaussian_rasterization_depth_alpha import GaussianRasterizer
+    sc, cam = small_scene(P=10, W=32, H=32, sh_degree=0)
+    rast = GaussianRasterizer(_settings(cam, (0, 0, 0), 0, "cuda"))
+    d = {k: v.cuda() for k, v in sc.items() if torch.is_tensor(v)}
+    with pytest.raises(Exception, match="SHs or precomputed colors"):
+        rast(means3D=d["means3D"], means2D=torch.zeros(10, 3).cuda(), opacities=d["opacities"], scales=d["scales"], rotations=d["rotations"])
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        rast(means3D=d["means3D"], means2D=torch.zeros(10, 3).cuda(), opacities=d["opacities"], shs=d["shs"])
+
+
+def test_multi_view_batch_matches_single_views():
+    """V views in one launch == V single-view calls; summed gradients == sum of per-view gradients."""
+    from ggsplat import rasterizer as R
+    from ggsplat import synthetic as S
+    dev = "cuda"
+    sc = S.random_gaussians(1500, sh_degree=2, seed=8)
+    sc["scales"] *= 5
+    cams = S.orbit_cameras(4, width=96, img_height=64, fx=100., fy=100., cx=47., cy=33.)
+    ck = S.stack_cameras(cams, device=dev)
+    args = [sc["means3D"].to(dev), sc["opacities"].to(dev), sc["shs"].to(dev), None, sc["scales"].to(dev), sc["rotations"].to(dev), None]
+    common = dict(bg=torch.tensor([0.1, 0.2, 0.3], device=dev), W=96, H=64, sh_degree=2)
+    color, radii, depth, alpha, st = R.forward_views(*args, view=ck["view"], proj=ck["proj"], campos=ck["campos"], tanfov=ck["tanfov"], **common)
+    g = torch.Generator().manual_seed(4)
+    dc = torch.randn(4, 3, 64, 96, generator=g).to(dev)
+    gb = R.backward_views(st, dc)
+    acc = None
+    for v in range(4):
+        c1, r1, d1, a1, s1 = R.forward_views(*args, view=ck["view"][v:v + 1], proj=ck["proj"][v:v + 1], campos=ck["campos"][v:v + 1],
+                                             tanfov=ck["tanfov"][v:v + 1], **common)
+        assert torch.equal(c1[0], color[v]) and torch.equal(r1[0], radii[v]) and torch.equal(d1[0], depth[v])
+        g1 = R.backward_views(s1, dc[v:v + 1])
+        assert rel_l1(g1["means2D"][0], gb["means2D"][v]) <= 1e-6
+        if acc is None:
+            acc = {k: t.clone() for k, t in g1.items() if k != "means2D"}
+        else:
+            for k in acc:
+                acc[k] += g1[k]
+    for k in acc:
+        assert rel_l1(gb[k], acc[k]) <= 1e-5, k
