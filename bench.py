@@ -1,0 +1,253 @@
+#!/usr/bin/env python
+"""bench.py -- forward+backward views/sec of the Gaussian-Garments render hot path on MI355X.
+
+Workload (BASELINE.json configs[1] / [2], SURVEY.md section 8d "config 2"): 100 000 mesh-bound
+Gaussians (skirt tube, one per face, through the fused mesh-binding kernel), 160 synthetic
+ActorsHQ-style 1920x1080 cameras, SH degree 0 (the s2_registration setting, s2_registration.py:158;
+--sh-degree 3 gives the s3 variant).  One "step" = the registration inner step over all 160 views:
+mesh binding forward, fwd+bwd render of every view with a dense seeded dL/dimage
+(loss = sum(w * image)), gradient accumulation over views, mesh-binding backward down to mesh.v,
+and (N > 1) one RCCL all-reduce of the flat gradient bucket.  Views are sharded views[rank::N]
+(strong scaling: total work per step is fixed at 160 views).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) including
+  roofline     -- dominant kernel: algorithmic bytes per launch / live HIP-event duration vs 8 TB/s
+  cpu_baseline -- the C oracle (oracle/splat_oracle.c, OpenMP) timed on the host cores on a
+                  bounded sample of the same views (kind "port").
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "gaussian-garments_amd"))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+KERNELS = ["preprocess", "scan_tiles", "scatter", "sort_tiles", "render_fwd", "render_bwd", "preprocess_bwd"]
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--views", type=int, default=160)
+    ap.add_argument("--sh-degree", type=int, default=0)
+    ap.add_argument("--chunk", type=int, default=32, help="views per launch set")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--n-around", type=int, default=200)
+    ap.add_argument("--n-rows", type=int, default=250)
+    ap.add_argument("--cpu-views", type=int, default=2, help="views of the workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--loop-views", type=int, default=16, help="views timed through the per-view drop-in render() loop")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    return ap.parse_args()
+
+
+def alg_bytes(P, K, P_vis, N, HW, T):
+    """Algorithmic (lower-bound) HBM bytes per view, per kernel group -- SURVEY.md section 8(d)."""
+    return {
+        "preprocess": P * (44 + 12 * K) + P * 4 + P_vis * 48,
+        "binning": N * 12 + N * 24,
+        "render_fwd": N * 44 + HW * 28 + T * 16,
+        "render_bwd": HW * 20 + N * 44 + P_vis * 36,
+        "preprocess_bwd": P * (44 + 12 * K) + P_vis * 84 + P * (56 + 12 * K),
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from ggsplat import batch, synthetic as S
+    from ggsplat import _lib
+    from ggsplat.dist import all_reduce_grads, shard_views
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    import ctypes as C
+
+    W, H, K = args.width, args.height, (args.sh_degree + 1) ** 2
+    verts, faces = S.skirt_mesh(args.n_around, args.n_rows)
+    Fn = faces.shape[0]
+    params = S.skirt_gaussian_params(Fn, sh_degree=args.sh_degree)
+    model = MeshGaussianModel.from_tensors(verts, faces, params, sh_degree=args.sh_degree, device=dev)
+    all_cams = S.rig_cameras(n_rings=max(1, args.views // 32), n_az=min(32, args.views), width=W, height=H)[:args.views]
+    n_views_total = len(all_cams) if args.scaling == "strong" else len(all_cams) * world
+    my = shard_views(len(all_cams), rank, world) if args.scaling == "strong" else list(range(len(all_cams)))
+    cams = S.stack_cameras([all_cams[i] for i in my], device=dev)
+    bg = torch.zeros(3, device=dev)
+    g = torch.Generator().manual_seed(1234)
+    w_img = torch.randn(3, H, W, generator=g).to(dev)
+    chunk = max(1, min(args.chunk, len(my)))
+    dL_buf = w_img.unsqueeze(0).expand(chunk, 3, H, W).contiguous()     # d(sum(w*image))/dimage, built once
+    plist = model.parameters()
+    stats = {}
+
+    def step():
+        model.update_face_coor()
+        xyz, scaling, rot = model.get_xyz, model.get_scaling, model.get_rotation     # ONE fused HIP kernel
+        opacity, shs = model.get_opacity, model.get_features
+        inputs = dict(means3D=xyz.detach(), scales=scaling.detach(), rotations=rot.detach(),
+                      opacities=opacity.detach(), shs=shs.detach())
+        gr = batch.fwd_bwd_views(inputs, cams, bg=bg, W=W, H=H, sh_degree=args.sh_degree, chunk=chunk,
+                                 dL_dcolor_fn=lambda v0, v1, color: dL_buf[:v1 - v0])
+        torch.autograd.backward([xyz, scaling, rot, opacity, shs],
+                                [gr["means3D"], gr["scales"], gr["rotations"], gr["opacities"], gr["shs"]])
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in plist]
+        all_reduce_grads(grads, n_views_total)
+        stats["num_rendered"] = gr["num_rendered"]
+        for p in plist:
+            p.grad = None
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    views_per_sec = n_views_total * args.steps / dt
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel durations (HIP events on the launch stream, one launch set of `chunk` views) ----
+        L = _lib.lib()
+        from ggsplat import rasterizer as R
+        model.update_face_coor()
+        with torch.no_grad():
+            inputs = dict(means3D=model.get_xyz.detach(), scales=model.get_scaling.detach(),
+                          rotations=model.get_rotation.detach(), opacities=model.get_opacity.detach(),
+                          shs=model.get_features.detach())
+        cs = {k: v[:chunk] for k, v in cams.items()}
+        reps, acc_ms = 5, [0.0] * len(KERNELS)
+        L.ggs_profile_enable(1)
+        P_vis = N_chunk = 0
+        for _ in range(reps):
+            color, radii, depth, alpha, st = R.forward_views(
+                inputs["means3D"], inputs["opacities"], inputs["shs"], None, inputs["scales"], inputs["rotations"], None,
+                view=cs["view"], proj=cs["proj"], campos=cs["campos"], tanfov=cs["tanfov"], bg=bg, W=W, H=H,
+                sh_degree=args.sh_degree)
+            buf = (C.c_float * 8)()
+            L.ggs_profile_read(buf, 8)
+            fwd_ms = list(buf)[:5]
+            R.backward_views(st, dL_buf[:chunk], want_means2D=False)
+            L.ggs_profile_read(buf, 8)
+            ms = fwd_ms + list(buf)[5:7]
+            acc_ms = [a + b for a, b in zip(acc_ms, ms)]
+            P_vis = float((radii > 0).sum().item()) / chunk
+            N_chunk = st.num_rendered
+            del st
+        L.ggs_profile_enable(0)
+        kern_ms = {k: v / reps for k, v in zip(KERNELS, acc_ms)}
+        N_view = N_chunk / chunk
+        T = ((W + 15) // 16) * ((H + 15) // 16)
+        B = alg_bytes(Fn, K, P_vis, N_view, W * H, T)
+        group_ms = {"preprocess": kern_ms["preprocess"],
+                    "binning": kern_ms["scan_tiles"] + kern_ms["scatter"] + kern_ms["sort_tiles"],
+                    "render_fwd": kern_ms["render_fwd"], "render_bwd": kern_ms["render_bwd"],
+                    "preprocess_bwd": kern_ms["preprocess_bwd"]}
+        dom = max(("render_fwd", "render_bwd", "preprocess", "preprocess_bwd"), key=lambda k: group_ms[k])
+        dom_bytes = B[dom] * chunk
+        achieved = dom_bytes / (group_ms[dom] * 1e-3) / 1e9
+        B_view = sum(B.values())
+        roofline = {"bound": "hbm", "kernel": "ggs_k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "launch_views": chunk, "launch_ms": round(group_ms[dom], 4),
+                    "alg_bytes_per_launch": int(dom_bytes),
+                    "kernel_ms_per_launch": {k: round(v, 4) for k, v in kern_ms.items()},
+                    "whole_path": {"alg_bytes_per_view": int(B_view),
+                                   "achieved_GBs": round(B_view * views_per_sec / 1e9, 2),
+                                   "frac": round(B_view * views_per_sec / 1e9 / HBM_PEAK_GBS, 5)}}
+
+        # ---- per-view drop-in loop (render() + autograd, one camera per call like the reference) ----
+        loop_vps = None
+        if args.loop_views > 0:
+            from ggsplat.render import render
+            from types import SimpleNamespace
+            pipe = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+            lcams = [all_cams[i] for i in my[:args.loop_views]]
+            for c in lcams:
+                for name in ("world_view_transform", "full_proj_transform", "camera_center", "projection_matrix"):
+                    setattr(c, name, getattr(c, name).to(dev))
+
+            def loop():
+                for c in lcams:
+                    model.update_face_coor()
+                    pkg = render(c, model, pipe, bg)
+                    (pkg["render"] * w_img).sum().backward()
+                    for p in plist:
+                        p.grad = None
+            loop()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            loop()
+            torch.cuda.synchronize(dev)
+            loop_vps = len(lcams) / (time.perf_counter() - t1)
+
+        # ---- CPU baseline: the C oracle on the host cores, bounded sample of the same views ----
+        cpu = None
+        if args.cpu_views > 0:
+            from oracle.c_oracle import COracle, build as build_oracle
+            build_oracle()
+            ci = {k: v.cpu() for k, v in inputs.items()}
+            n_cpu = min(args.cpu_views, len(my))
+            wc = w_img.cpu()
+            os.environ.setdefault("OMP_NUM_THREADS", str(os.cpu_count()))
+            t1 = time.perf_counter()
+            for i in range(n_cpu):
+                c = all_cams[my[i]]
+                co = COracle(means3D=ci["means3D"], opacities=ci["opacities"], shs=ci["shs"], scales=ci["scales"],
+                             rotations=ci["rotations"], viewmatrix=c.world_view_transform.cpu(),
+                             projmatrix=c.full_proj_transform.cpu(), campos=c.camera_center.cpu(), bg=torch.zeros(3),
+                             W=W, H=H, tanfovx=math.tan(c.FoVx * 0.5), tanfovy=math.tan(c.FoVy * 0.5),
+                             sh_degree=args.sh_degree)
+                co.backward(wc)
+                co.close()
+            cpu_dt = time.perf_counter() - t1
+            cpu = {"value": round(n_cpu / cpu_dt, 4), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
+                   "sample": f"{n_cpu} of the {len(all_cams)} views of the same workload, fwd+bwd, "
+                             f"oracle/splat_oracle.c with OpenMP on {os.cpu_count()} threads"}
+
+        out = {
+            "metric": "fwd+bwd views/sec @1080p, 100k mesh-Gaussians",
+            "value": round(views_per_sec, 2), "unit": "views/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{Fn} mesh-bound Gaussians (skirt tube, MeshGaussianModel), {len(all_cams)} synthetic "
+                                   f"{W}x{H} cameras, SH degree {args.sh_degree}, fwd+bwd with dense dL/dimage",
+                       "views_per_step": n_views_total, "views_per_launch": chunk, "parallelism": f"views sharded x{world}",
+                       "num_rendered_per_view": round(N_view, 1), "visible_per_view": round(P_vis, 1)},
+            "roofline": roofline, "cpu_baseline": cpu,
+            "per_view_loop_views_per_sec": None if loop_vps is None else round(loop_vps, 2),
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -11,12 +11,49 @@ namespace {
 
 thread_local char g_err[512] = "";
 
-int fail(int code, const char* fmt, ...) {
+}  // namespace
+
+// Records the thread-local error message; shared by every translation unit of the library.
+int ggs_fail_(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
+}
+void ggs_clear_error_() { g_err[0] = 0; }
+
+namespace {
+#define fail ggs_fail_
+
+// ---- optional per-kernel timing (bench.py roofline leg) ------------------------------------
+enum { K_PRE = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD, K_PRE_BWD, K_COUNT };
+struct Profile {
+    bool on = false, have = false;
+    hipEvent_t ev[K_COUNT][2];
+    bool used[K_COUNT] = {};
+    float ms[K_COUNT] = {};
+};
+thread_local Profile g_prof;
+
+void prof_start(int k, hipStream_t s) {
+    if (!g_prof.on) return;
+    if (!g_prof.have) {
+        for (int i = 0; i < K_COUNT; ++i) { hipEventCreate(&g_prof.ev[i][0]); hipEventCreate(&g_prof.ev[i][1]); }
+        g_prof.have = true;
+    }
+    hipEventRecord(g_prof.ev[k][0], s);
+}
+void prof_stop(int k, hipStream_t s) {
+    if (!g_prof.on) return;
+    hipEventRecord(g_prof.ev[k][1], s);
+    g_prof.used[k] = true;
+}
+void prof_collect(hipStream_t s) {
+    if (!g_prof.on) return;
+    hipStreamSynchronize(s);
+    for (int i = 0; i < K_COUNT; ++i)
+        if (g_prof.used[i]) { hipEventElapsedTime(&g_prof.ms[i], g_prof.ev[i][0], g_prof.ev[i][1]); g_prof.used[i] = false; }
 }
 
 // After each launch: always catch launch errors; in debug mode also sync and catch execution errors.
@@ -47,6 +84,7 @@ int check_params(const GgsParams* p) {
 
 int check_modes(const GgsParams* p, const void* shs, const void* colors, const void* scales, const void* rots,
                 const void* cov) {
+    if (p->P == 0) return GGS_OK;   // nothing to draw: empty inputs carry no mode
     if ((shs != nullptr) == (colors != nullptr))
         return fail(GGS_ERR_ARG, "Please provide excatly one of either SHs or precomputed colors!");
     if (((scales != nullptr) || (rots != nullptr)) == (cov != nullptr) || ((scales != nullptr) != (rots != nullptr)))
@@ -75,6 +113,14 @@ extern "C" {
 
 const char* ggs_last_error(void) { return g_err; }
 const char* ggs_version(void) { return "ggsplat 0.1 gfx950"; }
+
+int ggs_profile_enable(int on) { g_prof.on = on != 0; return GGS_OK; }
+
+int ggs_profile_read(float* ms, int n) {
+    if (!ms || n < K_COUNT) return fail(GGS_ERR_ARG, "ggs_profile_read: need room for %d floats", (int)K_COUNT);
+    for (int i = 0; i < K_COUNT; ++i) ms[i] = g_prof.ms[i];
+    return K_COUNT;
+}
 
 int ggs_workspace_sizes(const GgsParams* p, size_t bin_capacity, size_t* geom_bytes, size_t* img_bytes,
                         size_t* bin_bytes) {
@@ -140,21 +186,27 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
         a.scales = scales; a.rots = rotations; a.cov3d = cov3D_precomp;
         a.view = view; a.proj = proj; a.campos = campos; a.tanfov = tanfov;
         a.rec = (SplatRec*)geom; a.radii = radii; a.tile_count = tile_count;
+        prof_start(K_PRE, s);
         hipLaunchKernelGGL(ggs_k_preprocess, gridP, dim3(256), 0, s, a);
+        prof_stop(K_PRE, s);
         GGS_TRY(check("preprocess", s, p->debug));
     }
     {
         ScanArgs a;
         a.T = d.T; a.capacity = (unsigned long long)bin_capacity; a.tile_count = tile_count;
         a.tile_offset = tile_offset; a.view_base = view_base; a.header = header;
+        prof_start(K_SCAN, s);
         hipLaunchKernelGGL(ggs_k_scan_tiles, dim3((unsigned)V), dim3(1024), 0, s, a);
+        prof_stop(K_SCAN, s);
         GGS_TRY(check("scan_tiles", s, p->debug));
     }
     if (p->P > 0) {
         ScatterArgs a;
         a.P = p->P; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.rec = (const SplatRec*)geom; a.header = header;
         a.tile_cursor = tile_cursor; a.tile_offset = tile_offset; a.view_base = view_base; a.keys = keys;
+        prof_start(K_SCATTER, s);
         hipLaunchKernelGGL(ggs_k_scatter, gridP, dim3(256), 0, s, a);
+        prof_stop(K_SCATTER, s);
         GGS_TRY(check("scatter", s, p->debug));
     }
     const dim3 gridT((unsigned)d.T, (unsigned)V);
@@ -162,7 +214,9 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
         SortArgs a;
         a.T = d.T; a.header = header; a.tile_count = tile_count; a.tile_offset = tile_offset;
         a.view_base = view_base; a.keys = keys; a.ids = ids;
+        prof_start(K_SORT, s);
         hipLaunchKernelGGL(ggs_k_sort_tiles, gridT, dim3(256), 0, s, a);
+        prof_stop(K_SORT, s);
         GGS_TRY(check("sort_tiles", s, p->debug));
     }
     {
@@ -171,9 +225,12 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
         a.tile_count = tile_count; a.tile_offset = tile_offset; a.view_base = view_base; a.ids = ids;
         a.rec = (const SplatRec*)geom; a.bg = bg; a.out_color = out_color; a.out_depth = out_depth;
         a.out_alpha = out_alpha; a.final_T = final_T; a.n_contrib = n_contrib;
+        prof_start(K_RENDER_FWD, s);
         hipLaunchKernelGGL(ggs_k_render_fwd, gridT, dim3(256), 0, s, a);
+        prof_stop(K_RENDER_FWD, s);
         GGS_TRY(check("render_fwd", s, p->debug));
     }
+    prof_collect(s);
     return GGS_OK;
 }
 
@@ -218,8 +275,10 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
         a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth; a.dL_dalpha = dL_dalpha;
         a.acc = (GradRec*)scratch;
         const dim3 gridT((unsigned)d.T, (unsigned)V);
+        prof_start(K_RENDER_BWD, s);
         if (dL_ddepth || dL_dalpha) hipLaunchKernelGGL(ggs_k_render_bwd_da, gridT, dim3(256), 0, s, a);
         else hipLaunchKernelGGL(ggs_k_render_bwd, gridT, dim3(256), 0, s, a);
+        prof_stop(K_RENDER_BWD, s);
         GGS_TRY(check("render_bwd", s, p->debug));
     }
     {
@@ -231,9 +290,12 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
         a.rec = (const SplatRec*)geom; a.acc = (const GradRec*)scratch;
         a.dL_dmeans2D = dL_dmeans2D; a.dL_dmeans3D = dL_dmeans3D; a.dL_dopac = dL_dopacities; a.dL_dsh = dL_dshs;
         a.dL_dcolors = dL_dcolors; a.dL_dscales = dL_dscales; a.dL_drots = dL_drotations; a.dL_dcov3D = dL_dcov3D;
+        prof_start(K_PRE_BWD, s);
         hipLaunchKernelGGL(ggs_k_preprocess_bwd, dim3((unsigned)((p->P + 255) / 256)), dim3(256), 0, s, a);
+        prof_stop(K_PRE_BWD, s);
         GGS_TRY(check("preprocess_bwd", s, p->debug));
     }
+    prof_collect(s);
     return GGS_OK;
 }
 

@@ -91,3 +91,7 @@ __global__ void ggs_k_render_fwd(RenderArgs a);
 __global__ void ggs_k_render_bwd(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_da(RenderBwdArgs a);
 __global__ void ggs_k_preprocess_bwd(PreBwdArgs a);
+
+// host-side error plumbing (ggs_api.hip)
+int ggs_fail_(int code, const char* fmt, ...);
+void ggs_clear_error_();

@@ -37,6 +37,8 @@ _SIGS = {
     "ggs_backward": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 13 + [C.c_size_t] + [_PTR] * 13 + [C.c_int, _PTR]),
     "ggs_mesh_bind_forward": (C.c_int, [C.c_int, C.c_int] + [_PTR] * 11),
     "ggs_mesh_bind_backward": (C.c_int, [C.c_int, C.c_int] + [_PTR] * 15),
+    "ggs_profile_enable": (C.c_int, [C.c_int]),
+    "ggs_profile_read": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
     "ggs_last_error": (C.c_char_p, []),
     "ggs_version": (C.c_char_p, []),
 }

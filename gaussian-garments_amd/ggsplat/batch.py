@@ -1,0 +1,52 @@
+"""Multi-view batched forward+backward -- the throughput mode of the registration /
+appearance inner step (s2_registration.py:213-334, s3_appearance.py:107-149).
+
+The reference renders ONE camera per optimisation step.  For fixed parameters the views are
+independent, so this module renders a shard of views per launch set (grid dimension = view),
+accumulates the parameter gradients over all of them on the device, and (multi-GPU) sums the flat
+gradient bucket with a single RCCL all-reduce (ggsplat.dist).  Semantics: one optimiser step per
+batch of views instead of per view -- see DESIGN.md "multi-GPU".
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import rasterizer as R
+
+
+def fwd_bwd_views(inputs: Dict[str, torch.Tensor], cams: Dict[str, torch.Tensor], *, bg: torch.Tensor, W: int, H: int,
+                  sh_degree: int, dL_dcolor_fn, chunk: int = 32, keep_images: bool = False,
+                  want_means2D: bool = False) -> Dict[str, torch.Tensor]:
+    """inputs: activated rasterizer inputs {means3D, opacities, shs|colors_precomp, scales+rotations|cov3D_precomp}.
+    cams: stacked {view, proj, campos, tanfov} for this rank's views.
+    dL_dcolor_fn(v0, v1, color[v0:v1]) -> dL/dcolor [v1-v0,3,H,W] (the loss backward of those views).
+    Returns gradients w.r.t. the activated inputs, summed over all views (+ stats)."""
+    V = cams["view"].shape[0]
+    grads: Optional[Dict[str, torch.Tensor]] = None
+    n_total = 0
+    images: List[torch.Tensor] = []
+    for v0 in range(0, V, chunk):
+        v1 = min(V, v0 + chunk)
+        color, radii, depth, alpha, st = R.forward_views(
+            inputs["means3D"], inputs["opacities"], inputs.get("shs"), inputs.get("colors_precomp"),
+            inputs.get("scales"), inputs.get("rotations"), inputs.get("cov3D_precomp"),
+            view=cams["view"][v0:v1], proj=cams["proj"][v0:v1], campos=cams["campos"][v0:v1],
+            tanfov=cams["tanfov"][v0:v1], bg=bg, W=W, H=H, sh_degree=sh_degree)
+        n_total += st.num_rendered
+        dL = dL_dcolor_fn(v0, v1, color)
+        if grads is None:
+            grads = R.backward_views(st, dL, want_means2D=want_means2D)
+        else:
+            if want_means2D:
+                grads.pop("means2D", None)
+            R.backward_views(st, dL, want_means2D=want_means2D, out=grads, accumulate=True)
+        if keep_images:
+            images.append(color)
+        del st
+    grads = grads or {}
+    grads["num_rendered"] = n_total
+    if keep_images:
+        grads["images"] = torch.cat(images)
+    return grads

@@ -53,16 +53,11 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
         raise _lib.GgsError("ggsplat: tensors must live on the GPU (there is no CPU path in the product)")
     means3D, opacities, shs, colors_precomp = _f32c(means3D), _f32c(opacities), _f32c(shs), _f32c(colors_precomp)
     scales, rotations, cov3D_precomp = _f32c(scales), _f32c(rotations), _f32c(cov3D_precomp)
-    if shs is not None and shs.numel() == 0:
-        shs = None
-    if colors_precomp is not None and colors_precomp.numel() == 0:
-        colors_precomp = None
-    if scales is not None and scales.numel() == 0:
-        scales = None
-    if rotations is not None and rotations.numel() == 0:
-        rotations = None
-    if cov3D_precomp is not None and cov3D_precomp.numel() == 0:
-        cov3D_precomp = None
+    P = means3D.shape[0]
+    if P > 0:                                   # upstream convention: a missing input may arrive as an empty tensor
+        shs, colors_precomp, scales, rotations, cov3D_precomp = (
+            None if (t is not None and t.numel() == 0) else t
+            for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
     view = _f32c(view).reshape(-1, 16)
     V = view.shape[0]
     proj = _f32c(proj).reshape(V, 16)
@@ -70,7 +65,6 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
     tanfov = _f32c(tanfov).reshape(V, 2)
     bg = _f32c(bg).to(dev)
     bg = bg.reshape(1, 3).expand(V, 3).contiguous() if bg.numel() == 3 else bg.reshape(V, 3).contiguous()
-    P = means3D.shape[0]
     K = shs.shape[1] if shs is not None else 0
     prm = GgsParams(P, K, int(sh_degree), int(W), int(H), V, float(scale_modifier), 0, int(bool(debug)))
 

@@ -140,6 +140,14 @@ int ggs_mesh_bind_backward(int P, int F, const float* verts, const int64_t* face
                            const float* dL_drotation, float* dL_dverts, float* dL_dlocal_xyz,
                            float* dL_dlog_scaling, float* dL_draw_rot, void* stream);
 
+/* Profiling aid (bench.py roofline leg; not part of the reference's interface).  While enabled on the
+ * calling thread, ggs_forward / ggs_backward bracket each kernel with hipEvents on `stream`, synchronise
+ * once at the end of the call, and keep the per-kernel milliseconds of that call.  ggs_profile_read copies
+ * them out in the order {preprocess, scan_tiles, scatter, sort_tiles, render_fwd, render_bwd,
+ * preprocess_bwd} and returns the count (7). */
+int ggs_profile_enable(int on);
+int ggs_profile_read(float* ms, int n);
+
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* ggs_last_error(void);
 
