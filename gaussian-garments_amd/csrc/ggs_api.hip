@@ -155,8 +155,8 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
     g_err[0] = 0;
     GGS_TRY(check_params(p));
     GGS_TRY(check_modes(p, shs, colors_precomp, scales, rotations, cov3D_precomp));
-    if (!bg || !view || !proj || !campos || !tanfov || !geom || !bin || !img || !out_color || !out_depth ||
-        !out_alpha || (p->P > 0 && (!means3D || !opacities || !radii)))
+    if (!bg || !view || !proj || !campos || !tanfov || !bin || !img || !out_color || !out_depth ||
+        !out_alpha || (p->P > 0 && (!means3D || !opacities || !radii || !geom)))
         return fail(GGS_ERR_ARG, "ggs_forward: NULL pointer argument");
     hipStream_t s = (hipStream_t)stream_;
     const Dims d = dims(p);
@@ -244,9 +244,9 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
     g_err[0] = 0;
     GGS_TRY(check_params(p));
     GGS_TRY(check_modes(p, shs, colors_precomp, scales, rotations, cov3D_precomp));
+    if (p->P == 0) return GGS_OK;
     if (!bg || !view || !proj || !campos || !tanfov || !geom || !bin || !img || !dL_dcolor || !scratch)
         return fail(GGS_ERR_ARG, "ggs_backward: NULL pointer argument");
-    if (p->P == 0) return GGS_OK;
     if (!means3D || !dL_dmeans3D || !dL_dopacities) return fail(GGS_ERR_ARG, "ggs_backward: NULL gradient output");
     if (shs && !dL_dshs) return fail(GGS_ERR_ARG, "ggs_backward: dL_dshs is NULL but shs given");
     if (colors_precomp && !dL_dcolors) return fail(GGS_ERR_ARG, "ggs_backward: dL_dcolors is NULL but colors given");

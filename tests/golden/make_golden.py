@@ -1,0 +1,93 @@
+#!/usr/bin/env python
+"""Generates the golden vectors under tests/golden/ by IMPORTING the reference's own Python
+(utils/sh_utils.py, utils/graphics_utils.py, utils/loss_utils.py) from /root/reference.
+Runs only in the authoring container (the reference never travels to the GPU box); the .npz
+files it writes are data: seeded inputs + the reference's outputs.
+
+    python tests/golden/make_golden.py
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REF)
+
+from utils.sh_utils import eval_sh, RGB2SH, SH2RGB  # noqa: E402
+from utils.graphics_utils import (getWorld2View2, getProjectionMatrix, focal2fov, fov2focal,  # noqa: E402
+                                  compute_face_orientation)
+from utils.loss_utils import l1_loss, ssim  # noqa: E402
+
+
+def sh_golden():
+    g = torch.Generator().manual_seed(0)
+    sh = torch.randn(64, 3, 25, generator=g)                 # reference layout [..., C, K]
+    d = torch.nn.functional.normalize(torch.randn(64, 3, generator=g))
+    out = {f"deg{k}": eval_sh(k, sh, d).numpy() for k in range(5)}
+    rgb = torch.rand(16, 3, generator=g)
+    np.savez(os.path.join(OUT, "sh.npz"), sh=sh.numpy(), dirs=d.numpy(), rgb=rgb.numpy(),
+             rgb2sh=RGB2SH(rgb).numpy(), sh2rgb=SH2RGB(rgb).numpy(), **out)
+
+
+def camera_golden():
+    rng = np.random.default_rng(1)
+    rec = {}
+    for i in range(4):
+        A = rng.normal(size=(3, 3))
+        Q, _ = np.linalg.qr(A)
+        if np.linalg.det(Q) < 0:
+            Q[:, 0] *= -1
+        T = rng.normal(size=3) * 2
+        w, h = [(640, 480), (1920, 1080), (940, 1280), (512, 512)][i]
+        fx, fy = 500.0 + 300 * i, 520.0 + 280 * i
+        cx, cy = w / 2 + rng.uniform(-20, 20), h / 2 + rng.uniform(-20, 20)
+        trans, scale = (np.array([0.1, -0.2, 0.3]), 1.5) if i == 3 else (np.array([0.0, 0.0, 0.0]), 1.0)
+        fovx, fovy = focal2fov(fx, w), focal2fov(fy, h)
+        w2c = getWorld2View2(Q, T, trans, scale)
+        proj = getProjectionMatrix(znear=0.01, zfar=100.0, fovX=fovx, fovY=fovy, fx=fx, fy=fy, cx=cx, cy=cy, w=w, h=h)
+        wvt = torch.tensor(w2c).transpose(0, 1)
+        full = (wvt.unsqueeze(0).bmm(proj.transpose(0, 1).unsqueeze(0))).squeeze(0)     # scene/cameras.py:59-61
+        center = wvt.inverse()[3, :3]
+        rec[f"R{i}"], rec[f"T{i}"] = Q, T
+        rec[f"intr{i}"] = np.array([fx, fy, cx, cy, w, h, scale, *trans])
+        rec[f"fov{i}"] = np.array([fovx, fovy, fov2focal(fovx, w), fov2focal(fovy, h)])
+        rec[f"w2c{i}"], rec[f"proj{i}"] = w2c, proj.numpy()
+        rec[f"wvt{i}"], rec[f"full{i}"], rec[f"center{i}"] = wvt.numpy(), full.numpy(), center.numpy()
+    np.savez(os.path.join(OUT, "cameras.npz"), **rec)
+
+
+def face_golden():
+    g = torch.Generator().manual_seed(2)
+    v = torch.randn(40, 3, generator=g)
+    f = torch.stack([torch.randperm(40, generator=g)[:3] for _ in range(32)])
+    R, s = compute_face_orientation(v, f, return_scale=True)
+    np.savez(os.path.join(OUT, "face_orientation.npz"), verts=v.numpy(), faces=f.numpy(), orientation=R.numpy(),
+             scale=s.numpy())
+
+
+def loss_golden():
+    g = torch.Generator().manual_seed(3)
+    a = torch.rand(3, 48, 64, generator=g)
+    b = torch.rand(3, 48, 64, generator=g)
+    m = (torch.rand(1, 48, 64, generator=g) > 0.3).float()
+    rec = dict(img1=a.numpy(), img2=b.numpy(), mask=m.numpy())
+    for tag, mask in (("nomask", None), ("mask", m)):
+        x = a.clone().requires_grad_(True)
+        l1 = l1_loss(x, b, mask)
+        l1.backward()
+        rec[f"l1_{tag}"], rec[f"l1_grad_{tag}"] = l1.item(), x.grad.numpy().copy()
+        x = a.clone().requires_grad_(True)
+        x1 = x + 0                                   # ssim masks img1 / img2 IN PLACE (loss_utils.py:44-46)
+        s = ssim(x1, b.clone(), mask)
+        s.backward()
+        rec[f"ssim_{tag}"], rec[f"ssim_grad_{tag}"] = s.item(), x.grad.numpy().copy()
+    np.savez(os.path.join(OUT, "loss.npz"), **rec)
+
+
+if __name__ == "__main__":
+    sh_golden(); camera_golden(); face_golden(); loss_golden()
+    print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))

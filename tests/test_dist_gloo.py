@@ -1,0 +1,84 @@
+"""Multi-GPU path on CPU: world_size-2 gloo process group, view sharding + one flat-bucket
+all-reduce of the gradients (ggsplat.dist), exactly the code bench.py runs over RCCL."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ggsplat.dist import all_reduce_densification_stats, all_reduce_grads, flatten_grads, shard_views, unflatten_into
+
+
+def test_shard_views_partition():
+    for world in (1, 2, 4, 8):
+        got = sorted(v for r in range(world) for v in shard_views(160, r, world))
+        assert got == list(range(160))
+        sizes = [len(shard_views(160, r, world)) for r in range(world)]
+        assert max(sizes) - min(sizes) <= 1
+    assert shard_views(5, 3, 8) == [3] and shard_views(5, 7, 8) == []
+
+
+def test_flatten_roundtrip():
+    ts = [torch.randn(5, 3), torch.randn(7), torch.randn(2, 4, 3)]
+    flat = flatten_grads(ts)
+    assert flat.numel() == 15 + 7 + 24
+    out = [torch.zeros_like(t) for t in ts]
+    unflatten_into(flat, out)
+    assert all(torch.equal(a, b) for a, b in zip(ts, out))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # per-view "gradients": deterministic function of the view index, so the exact sum is known
+    views = shard_views(10, rank, world)
+    shapes = [(6, 3), (6, 1), (6, 1, 3), (4, 3)]
+    grads = [torch.zeros(s) for s in shapes]
+    for v in views:
+        g = torch.Generator().manual_seed(100 + v)
+        for t in grads:
+            t += torch.randn(t.shape, generator=g)
+    flat = all_reduce_grads(grads, n_views_total=10, average=True)
+    acc, den, rad = torch.full((6, 1), float(rank + 1)), torch.ones(6, 1), torch.tensor([1.0 + rank, 5.0 - rank])
+    all_reduce_densification_stats(acc, den, rad)
+    q.put((rank, [t.clone() for t in grads], flat.numel(), acc.clone(), den.clone(), rad.clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_all_reduce_matches_single_process():
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    shapes = [(6, 3), (6, 1), (6, 1, 3), (4, 3)]
+    expect = [torch.zeros(s) for s in shapes]
+    for v in range(10):
+        g = torch.Generator().manual_seed(100 + v)
+        for t in expect:
+            t += torch.randn(t.shape, generator=g)
+    expect = [t / 10.0 for t in expect]
+    for rank, grads, n, acc, den, rad in res:
+        assert n == sum(torch.Size(s).numel() for s in shapes)
+        for a, b in zip(grads, expect):
+            assert torch.allclose(a, b, atol=1e-6)
+        assert torch.equal(acc, torch.full((6, 1), 3.0)) and torch.equal(den, torch.full((6, 1), 2.0))
+        assert torch.equal(rad, torch.tensor([2.0, 5.0]))
+    # both ranks end with identical gradients -> identical Adam steps without a parameter broadcast
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.equal(a, b)

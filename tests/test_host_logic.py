@@ -1,0 +1,131 @@
+"""Host-side logic that needs no GPU: synthetic workloads, the render() mirror's selection logic
+(with the native rasterizer stubbed out), camera helpers."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+
+from ggsplat import synthetic as S
+from ggsplat import cameras as CAM
+
+
+def test_config2_sizes():
+    v, f = S.skirt_mesh()
+    assert v.shape == (50200, 3) and f.shape == (100000, 3)
+    assert int(f.max()) == 50199 and int(f.min()) == 0
+    e1, e2 = v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]
+    assert float(torch.linalg.cross(e1, e2).norm(dim=1).min()) > 0   # no degenerate faces
+    p = S.skirt_gaussian_params(100000, sh_degree=3)
+    assert p["_features_rest"].shape == (100000, 15, 3) and p["binding"].dtype == torch.int64
+    cams = S.rig_cameras()
+    assert len(cams) == 160 and cams[0].image_width == 1920 and cams[0].image_height == 1080
+    c = S.stack_cameras(cams[:3])
+    assert c["view"].shape == (3, 16) and c["tanfov"].shape == (3, 2)
+    assert abs(float(c["tanfov"][0, 0]) - 960 / 1500) < 1e-6
+
+
+def test_look_at_camera_sees_target_at_principal_point():
+    cam = CAM.look_at_camera((2.5, 0.7, 0.3), (0, 1, 0), width=1920, height=1080, fx=1500., fy=1500., cx=955., cy=548., device="cpu")
+    hom = torch.tensor([[0.0, 1.0, 0.0, 1.0]]) @ cam.full_proj_transform
+    ndc = hom[0, :2] / hom[0, 3]
+    assert abs(float(((ndc[0] + 1) * 1920 - 1) / 2) - (955 - 0.5)) < 1e-2
+    assert abs(float(((ndc[1] + 1) * 1080 - 1) / 2) - (548 - 0.5)) < 1e-2
+    assert np.allclose(cam.camera_center.numpy(), [2.5, 0.7, 0.3], atol=1e-5)
+    # +y of the image points down in the world
+    up = torch.tensor([[0.0, 1.2, 0.0, 1.0]]) @ cam.full_proj_transform
+    assert float(up[0, 1] / up[0, 3]) < float(ndc[1])
+
+
+class _StubRasterizer:
+    calls = []
+
+    def __init__(self, raster_settings):
+        self.rs = raster_settings
+
+    def __call__(self, **kw):
+        _StubRasterizer.calls.append((self.rs, kw))
+        P = kw["means3D"].shape[0]
+        H, W = self.rs.image_height, self.rs.image_width
+        return torch.zeros(3, H, W), torch.arange(P, dtype=torch.int32) % 2, torch.zeros(1, H, W), torch.zeros(1, H, W)
+
+
+@pytest.fixture
+def render_mod(monkeypatch):
+    from ggsplat import render as RM
+    monkeypatch.setattr(RM, "GaussianRasterizer", _StubRasterizer)
+    _StubRasterizer.calls.clear()
+    return RM
+
+
+def _pc(P=6, K=4, with_shs=False, with_local=False):
+    pc = SimpleNamespace(_xyz=torch.zeros(P, 3), active_sh_degree=1, max_sh_degree=1,
+                         get_xyz=torch.randn(P, 3), get_opacity=torch.rand(P, 1), get_scaling=torch.rand(P, 3),
+                         get_rotation=torch.randn(P, 4), get_features=torch.randn(P, K, 3),
+                         get_covariance=lambda m: torch.full((P, 6), float(m)))
+    if with_shs:
+        pc.shs = torch.randn(P, K, 3)
+    if with_local:
+        pc.local_xyz = torch.randn(P, 3)
+        pc.get_final_xyz = torch.randn(P, 3) + 10
+    return pc
+
+
+def test_render_mirror_default_path(render_mod):
+    cam = S.orbit_cameras(1, width=64, img_height=48)[0]
+    pipe = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    pc = _pc()
+    out = render_mod.render(cam, pc, pipe, torch.zeros(3))
+    rs, kw = _StubRasterizer.calls[-1]
+    assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii", "3dposition", "depth", "alpha"}
+    assert rs.image_height == 48 and rs.image_width == 64 and rs.sh_degree == 1 and rs.prefiltered is False
+    assert abs(rs.tanfovx - math.tan(cam.FoVx * 0.5)) < 1e-12
+    assert kw["shs"] is pc.get_features and kw["colors_precomp"] is None
+    assert kw["scales"] is pc.get_scaling and kw["rotations"] is pc.get_rotation and kw["cov3D_precomp"] is None
+    assert kw["means3D"] is pc.get_xyz and kw["means2D"].requires_grad
+    assert out["visibility_filter"].dtype == torch.bool and out["viewspace_points"] is kw["means2D"]
+
+
+def test_render_mirror_s3_selection_and_vis_mask(render_mod):
+    cam = S.orbit_cameras(1, width=32, img_height=32)[0]
+    pipe = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    pc = _pc(with_shs=True, with_local=True)
+    mask = torch.tensor([1, 0, 1, 1, 0, 0], dtype=torch.bool)
+    out = render_mod.render(cam, pc, pipe, torch.zeros(3), vis_mask=mask)
+    _, kw = _StubRasterizer.calls[-1]
+    assert torch.equal(kw["means3D"], pc.get_final_xyz[mask])           # get_final_xyz when local_xyz is set
+    assert torch.equal(kw["shs"], pc.shs[mask])                          # pc.shs wins over get_features
+    assert kw["opacities"].shape == (3, 1) and kw["scales"].shape == (3, 3) and kw["means2D"].shape == (3, 3)
+    assert out["radii"].shape == (3,)
+
+
+def test_render_mirror_python_paths_and_override(render_mod):
+    cam = S.orbit_cameras(1, width=32, img_height=32)[0]
+    pc = _pc()
+    pipe = SimpleNamespace(debug=True, compute_cov3D_python=True, convert_SHs_python=True)
+    render_mod.render(cam, pc, pipe, torch.zeros(3), scaling_modifier=0.5)
+    rs, kw = _StubRasterizer.calls[-1]
+    assert rs.debug is True and rs.scale_modifier == 0.5
+    assert kw["scales"] is None and torch.equal(kw["cov3D_precomp"], torch.full((6, 6), 0.5))
+    assert kw["shs"] is None and kw["colors_precomp"].shape == (6, 3) and float(kw["colors_precomp"].min()) >= 0
+    col = torch.rand(6, 3)
+    render_mod.render(cam, pc, SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False),
+                      torch.zeros(3), override_color=col)
+    assert _StubRasterizer.calls[-1][1]["colors_precomp"] is col
+
+
+def test_dropin_module_signature_and_errors():
+    import diff_gaussian_rasterization_depth_alpha as D
+    assert D.GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered", "debug")
+    rs = D.GaussianRasterizationSettings(8, 8, 1., 1., torch.zeros(3), 1., torch.eye(4), torch.eye(4), 0, torch.zeros(3), False, False)
+    r = D.GaussianRasterizer(raster_settings=rs)
+    z = torch.zeros(2, 3)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(means3D=z, means2D=z, opacities=torch.zeros(2, 1), shs=torch.zeros(2, 1, 3), colors_precomp=z, scales=z, rotations=torch.zeros(2, 4))
+    with pytest.raises(Exception, match="exactly one of either scale/rotation pair"):
+        r(means3D=z, means2D=z, opacities=torch.zeros(2, 1), shs=torch.zeros(2, 1, 3), scales=z, rotations=torch.zeros(2, 4), cov3D_precomp=torch.zeros(2, 6))
+    vis = r.markVisible(torch.tensor([[0.0, 0, 1.0], [0.0, 0, 0.1]]))
+    assert vis.tolist() == [True, False]
