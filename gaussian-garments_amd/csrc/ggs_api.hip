@@ -127,7 +127,7 @@ int ggs_workspace_sizes(const GgsParams* p, size_t bin_capacity, size_t* geom_by
     GGS_TRY(check_params(p));
     const Dims d = dims(p);
     const size_t V = (size_t)p->n_views;
-    if (geom_bytes) *geom_bytes = ggs_align(V * (size_t)p->P * sizeof(SplatRec));
+    if (geom_bytes) *geom_bytes = ggs_align(V * (size_t)p->P * sizeof(SplatRec)) + ggs_align(V * (size_t)p->P * sizeof(SplatAux));
     if (img_bytes) *img_bytes = ggs_align(V * (size_t)p->W * p->H * 4) * 2;
     if (bin_bytes) *bin_bytes = ggs_bin_layout(p->n_views, d.T, bin_capacity).total;
     return GGS_OK;
@@ -185,7 +185,8 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
         a.means3D = means3D; a.shs = shs; a.colors = colors_precomp; a.opacities = opacities;
         a.scales = scales; a.rots = rotations; a.cov3d = cov3D_precomp;
         a.view = view; a.proj = proj; a.campos = campos; a.tanfov = tanfov;
-        a.rec = (SplatRec*)geom; a.radii = radii; a.tile_count = tile_count;
+        a.rec = (SplatRec*)geom; a.aux = (SplatAux*)((char*)geom + ggs_align((size_t)V * p->P * sizeof(SplatRec)));
+        a.radii = radii; a.tile_count = tile_count;
         prof_start(K_PRE, s);
         hipLaunchKernelGGL(ggs_k_preprocess, gridP, dim3(256), 0, s, a);
         prof_stop(K_PRE, s);
@@ -203,6 +204,7 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
     if (p->P > 0) {
         ScatterArgs a;
         a.P = p->P; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.rec = (const SplatRec*)geom; a.header = header;
+        a.aux = (const SplatAux*)((const char*)geom + ggs_align((size_t)V * p->P * sizeof(SplatRec)));
         a.tile_cursor = tile_cursor; a.tile_offset = tile_offset; a.view_base = view_base; a.keys = keys;
         prof_start(K_SCATTER, s);
         hipLaunchKernelGGL(ggs_k_scatter, gridP, dim3(256), 0, s, a);
@@ -226,7 +228,7 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
         a.rec = (const SplatRec*)geom; a.bg = bg; a.out_color = out_color; a.out_depth = out_depth;
         a.out_alpha = out_alpha; a.final_T = final_T; a.n_contrib = n_contrib;
         prof_start(K_RENDER_FWD, s);
-        hipLaunchKernelGGL(ggs_k_render_fwd, gridT, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(ggs_k_render_fwd, dim3((unsigned)(8 * d.gx * ((d.gy + 7) / 8)), (unsigned)V), dim3(64), 0, s, a);
         prof_stop(K_RENDER_FWD, s);
         GGS_TRY(check("render_fwd", s, p->debug));
     }
@@ -274,10 +276,10 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
         a.n_contrib = (const uint32_t*)((const char*)img + ggs_align((size_t)V * HW * 4));
         a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth; a.dL_dalpha = dL_dalpha;
         a.acc = (GradRec*)scratch;
-        const dim3 gridT((unsigned)d.T, (unsigned)V);
+        const dim3 gridT((unsigned)(8 * d.gx * ((d.gy + 7) / 8)), (unsigned)V);   // one wave64 per tile, tile rows interleaved over XCDs
         prof_start(K_RENDER_BWD, s);
-        if (dL_ddepth || dL_dalpha) hipLaunchKernelGGL(ggs_k_render_bwd_da, gridT, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(ggs_k_render_bwd, gridT, dim3(256), 0, s, a);
+        if (dL_ddepth || dL_dalpha) hipLaunchKernelGGL(ggs_k_render_bwd_da, gridT, dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(ggs_k_render_bwd, gridT, dim3(64), 0, s, a);
         prof_stop(K_RENDER_BWD, s);
         GGS_TRY(check("render_bwd", s, p->debug));
     }
@@ -288,6 +290,7 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
         a.means3D = means3D; a.shs = shs; a.colors = colors_precomp; a.scales = scales; a.rots = rotations;
         a.cov3d = cov3D_precomp; a.view = view; a.proj = proj; a.campos = campos; a.tanfov = tanfov;
         a.rec = (const SplatRec*)geom; a.acc = (const GradRec*)scratch;
+        a.aux = (const SplatAux*)((const char*)geom + ggs_align((size_t)V * p->P * sizeof(SplatRec)));
         a.dL_dmeans2D = dL_dmeans2D; a.dL_dmeans3D = dL_dmeans3D; a.dL_dopac = dL_dopacities; a.dL_dsh = dL_dshs;
         a.dL_dcolors = dL_dcolors; a.dL_dscales = dL_dscales; a.dL_drots = dL_drotations; a.dL_dcov3D = dL_dcov3D;
         prof_start(K_PRE_BWD, s);

@@ -3,7 +3,8 @@
 // HBM layouts (all per call, caller-allocated, see include/ggsplat.h):
 //   geom : SplatRec rec[V][P]            48 B per (view, Gaussian), AoS so that the
 //                                        render kernels gather one record = 3 x 16 B
-//                                        from one or two cache lines.
+//                                        from one or two cache lines;
+//          SplatAux aux[V][P]            8 B: radius + SH clamp bits (binning / backward only).
 //   bin  : BinHeader | tile_count[V][T] | tile_cursor[V][T] | tile_offset[V][T] |
 //          view_base[V] | keys[cap] (u64: depth bits << 32 | Gaussian id) | ids[cap] (u32)
 //   img  : final_T[V][H*W] f32 | n_contrib[V][H*W] u32
@@ -35,10 +36,16 @@ struct SplatRec {                // float index
     float px, py, cx, cy;        // 0..3   pixel mean, conic.x, conic.y
     float cz, opacity, r, g;     // 4..7   conic.z, opacity, colour r, g
     float b, depth;              // 8..9   colour b, view-space depth
-    int radius;                  // 10     3-sigma radius in px; 0 = culled
-    unsigned clamped;            // 11     bit c set: SH colour channel c was clamped at 0
+    unsigned bbx, bby;           // 10..11 pixel AABB of the region where alpha can reach 1/255:
+                                 //        int16 min | int16 max << 16 (conservative; empty if min > max)
 };
 static_assert(sizeof(SplatRec) == 48, "SplatRec must be 48 bytes");
+
+struct SplatAux {
+    int radius;                  // 3-sigma radius in px (the `radii` output); 0 = culled
+    unsigned clamped;            // bit c set: SH colour channel c was clamped at 0
+};
+static_assert(sizeof(SplatAux) == 8, "SplatAux must be 8 bytes");
 
 struct GradRec {                 // per-(view, Gaussian) gradient accumulators
     float mx, my;                // d/d(pixel mean)
@@ -86,6 +93,36 @@ __device__ __forceinline__ void ggs_tile_rect(float px, float py, float r, int g
     y0 = b0 < 0 ? 0 : (b0 > gy ? gy : b0);
     x1 = a1 < 0 ? 0 : (a1 > gx ? gx : a1);
     y1 = b1 < 0 ? 0 : (b1 > gy ? gy : b1);
+}
+
+// Conservative pixel AABB of {alpha >= 1/255} for a splat: d^T C d <= 2 tau with
+// tau = ln(255 opacity), so |dx| <= sqrt(2 tau Sigma_xx).  Margins make it a strict superset of
+// what the per-pixel fp32 test accepts, so using it to skip work never changes a result.
+__device__ __forceinline__ void ggs_alpha_bbox(float px, float py, float var_x, float var_y, float opacity,
+                                               unsigned& bbx, unsigned& bby) {
+    const float tau = (opacity > 0.f ? logf(255.f * opacity) : -1.f) * 1.01f + 0.02f;
+    int xmin = 1, xmax = 0, ymin = 1, ymax = 0;
+    if (tau > 0.f) {
+        const float ex = sqrtf(2.f * tau * var_x) * 1.001f + 0.01f;
+        const float ey = sqrtf(2.f * tau * var_y) * 1.001f + 0.01f;
+        const float lo = -32768.f, hi = 32767.f;
+        xmin = (int)ggs_max(lo, ggs_min(hi, floorf(px - ex)));
+        xmax = (int)ggs_max(lo, ggs_min(hi, ceilf(px + ex)));
+        ymin = (int)ggs_max(lo, ggs_min(hi, floorf(py - ey)));
+        ymax = (int)ggs_max(lo, ggs_min(hi, ceilf(py + ey)));
+    }
+    bbx = ((unsigned)xmin & 0xffffu) | ((unsigned)xmax << 16);
+    bby = ((unsigned)ymin & 0xffffu) | ((unsigned)ymax << 16);
+}
+__device__ __forceinline__ int ggs_bb_min(unsigned w) { return (int)(w << 16) >> 16; }
+__device__ __forceinline__ int ggs_bb_max(unsigned w) { return (int)w >> 16; }
+
+// Tiles of the reference rectangle [x0,x1) x [y0,y1) that the alpha AABB can reach.
+__device__ __forceinline__ void ggs_cull_rect(unsigned bbx, unsigned bby, int& x0, int& y0, int& x1, int& y1) {
+    const int tx0 = ggs_bb_min(bbx) >> 4, tx1 = (ggs_bb_max(bbx) >> 4) + 1;
+    const int ty0 = ggs_bb_min(bby) >> 4, ty1 = (ggs_bb_max(bby) >> 4) + 1;
+    x0 = x0 > tx0 ? x0 : tx0; x1 = x1 < tx1 ? x1 : tx1;
+    y0 = y0 > ty0 ? y0 : ty0; y1 = y1 < ty1 ? y1 : ty1;
 }
 
 // Rotation matrix (row-major) of a (w,x,y,z) quaternion, no normalisation (A.0).

@@ -8,6 +8,7 @@ struct PreArgs {
     const float *means3D, *shs, *colors, *opacities, *scales, *rots, *cov3d;
     const float *view, *proj, *campos, *tanfov;
     SplatRec* rec;
+    SplatAux* aux;
     int* radii;
     uint32_t* tile_count;
 };
@@ -24,6 +25,7 @@ struct ScanArgs {
 struct ScatterArgs {
     int P, gx, gy, T;
     const SplatRec* rec;
+    const SplatAux* aux;
     const GgsBinHeader* header;
     uint32_t* tile_cursor;
     const uint32_t* tile_offset;
@@ -79,6 +81,7 @@ struct PreBwdArgs {
     const float *means3D, *shs, *colors, *scales, *rots, *cov3d;
     const float *view, *proj, *campos, *tanfov;
     const SplatRec* rec;
+    const SplatAux* aux;
     const GradRec* acc;
     float *dL_dmeans2D, *dL_dmeans3D, *dL_dopac, *dL_dsh, *dL_dcolors, *dL_dscales, *dL_drots, *dL_dcov3D;
 };

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
     int radius = 0;
     SplatRec out;
     out.px = out.py = out.cx = out.cy = out.cz = out.opacity = out.r = out.g = out.b = out.depth = 0.f;
-    out.clamped = 0;
+    out.bbx = 0x00000001u; out.bby = 0x00000001u;   // empty AABB (min 1 > max 0)
+    unsigned clamped = 0;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
 
     const float m[3] = {a.means3D[3 * (size_t)g], a.means3D[3 * (size_t)g + 1], a.means3D[3 * (size_t)g + 2]};
@@ -92,6 +93,7 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
                 out.cx = cc * det_inv; out.cy = -cb * det_inv; out.cz = ca * det_inv;
                 out.opacity = a.opacities[g];
                 out.depth = pvz;
+                ggs_alpha_bbox(px, py, ca, cc, out.opacity, out.bbx, out.bby);
                 if (a.colors) {
                     out.r = a.colors[3 * (size_t)g]; out.g = a.colors[3 * (size_t)g + 1]; out.b = a.colors[3 * (size_t)g + 2];
                 } else {
@@ -102,22 +104,24 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
                     const float* sh = a.shs + (size_t)g * a.K * 3;
                     float rgb[3];
                     switch (a.deg) {
-                        case 0: sh_to_rgb<0>(sh, d, rgb, out.clamped); break;
-                        case 1: sh_to_rgb<1>(sh, d, rgb, out.clamped); break;
-                        case 2: sh_to_rgb<2>(sh, d, rgb, out.clamped); break;
-                        default: sh_to_rgb<3>(sh, d, rgb, out.clamped); break;
+                        case 0: sh_to_rgb<0>(sh, d, rgb, clamped); break;
+                        case 1: sh_to_rgb<1>(sh, d, rgb, clamped); break;
+                        case 2: sh_to_rgb<2>(sh, d, rgb, clamped); break;
+                        default: sh_to_rgb<3>(sh, d, rgb, clamped); break;
                     }
                     out.r = rgb[0]; out.g = rgb[1]; out.b = rgb[2];
                 }
             }
         }
     }
-    out.radius = radius;
     a.radii[vg] = radius;
+    SplatAux ax; ax.radius = radius; ax.clamped = clamped;
+    a.aux[vg] = ax;
     float4* dst = reinterpret_cast<float4*>(rec);
     const float4* src = reinterpret_cast<const float4*>(&out);
     dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
     if (radius > 0) {
+        ggs_cull_rect(out.bbx, out.bby, x0, y0, x1, y1);
         uint32_t* cnt = a.tile_count + (size_t)v * a.T;
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) atomicAdd(&cnt[y * gx + x], 1u);
@@ -135,10 +139,11 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
     const SplatRec* rec = a.rec + (size_t)v * a.P + g;
     const float4 r0 = reinterpret_cast<const float4*>(rec)[0];
     const float4 r2 = reinterpret_cast<const float4*>(rec)[2];
-    const int radius = __float_as_int(r2.z);
+    const int radius = a.aux[(size_t)v * a.P + g].radius;
     if (radius <= 0) return;
     int x0, y0, x1, y1;
     ggs_tile_rect(r0.x, r0.y, (float)radius, a.gx, a.gy, x0, y0, x1, y1);
+    ggs_cull_rect(__float_as_uint(r2.z), __float_as_uint(r2.w), x0, y0, x1, y1);
     const unsigned long long key = ((unsigned long long)__float_as_uint(r2.y) << 32) | (unsigned)g;
     uint32_t* cur = a.tile_cursor + (size_t)v * a.T;
     const uint32_t* off = a.tile_offset + (size_t)v * a.T;
@@ -233,8 +238,8 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess_bwd(PreBwdArgs a) {
     for (int v = 0; v < a.V; ++v) {
         const size_t vg = (size_t)v * a.P + g;
         const float4* rp = reinterpret_cast<const float4*>(a.rec + vg);
-        const float4 r2 = rp[2];
-        const int radius = __float_as_int(r2.z);
+        const SplatAux ax = a.aux[vg];
+        const int radius = ax.radius;
         float* o2 = a.dL_dmeans2D ? a.dL_dmeans2D + 3 * vg : nullptr;
         if (radius <= 0) {
             if (o2) { o2[0] = 0.f; o2[1] = 0.f; o2[2] = 0.f; }
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess_bwd(PreBwdArgs a) {
         if (a.colors) {
             dcol[0] += grgb[0]; dcol[1] += grgb[1]; dcol[2] += grgb[2];
         } else if (dsh) {
-            const unsigned clamped = __float_as_uint(r2.w);
+            const unsigned clamped = ax.clamped;
             const float gsh[3] = {(clamped & 1u) ? 0.f : grgb[0], (clamped & 2u) ? 0.f : grgb[1], (clamped & 4u) ? 0.f : grgb[2]};
             const float* campos = a.campos + 3 * v;
             float d[3] = {m[0] - campos[0], m[1] - campos[1], m[2] - campos[2]};

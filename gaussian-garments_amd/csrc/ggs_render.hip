@@ -1,16 +1,23 @@
 // ggs_render.hip -- per-tile front-to-back compositing (forward) and the per-pixel
 // reverse walk that accumulates per-splat gradients (backward).
 //
-// One workgroup = one 16x16 tile = 4 wave64; wave w owns the 8x8 quadrant
-// (w&1, w>>1) so that a splat's footprint test is as wave-coherent as possible
-// (the exec-mask skip of a whole quadrant is the common case).  The tile's
-// depth-sorted splat list is staged through LDS in rounds of GGS_BATCH records
-// (48 B each, read back with broadcast ds_read_b128).
+// CDNA4 mapping: ONE wave64 owns ONE 16x16 tile.  Lane l holds 4 pixels, one in each 8x8
+// quadrant q of the tile (x = 8(q&1) + (l&7), y = 8(q>>1) + (l>>3)), so a quadrant a splat
+// does not reach is skipped with a single exec-mask branch, exactly like a 4-wave block
+// would skip a wave -- but the per-splat overhead (record fetch, loop, reduction) is paid
+// once per tile instead of four times, and there is no LDS staging and no barrier at all:
+//   * the tile's depth-sorted id list is walked in rounds of 64: lane i gathers the 48-byte
+//     record of splat (base + i) with three 16-byte loads (the next round is prefetched while
+//     the current one is composited);
+//   * splat j of the round is broadcast to the wave with v_readlane (SGPR operands feed the
+//     VALU directly);
+//   * backward: the 4 pixels of a lane are summed in registers, one DPP wave reduction
+//     (row_shr + row_bcast) per value yields the tile total in lane 63, which issues the
+//     global float atomics (one per splat, tile and value).
 //
-// Roofline: HBM is the nominal bound (algorithmic bytes: N*48 B record gathers +
-// 28 B/pixel of outputs forward; N*48 + 20 B/pixel + N*40 B of gradient atomics
-// backward), but with LDS staging the kernels are VALU/exp bound: ~25 VALU ops per
-// (pixel, splat) forward, ~50 + 60 (wave reduction) backward.
+// Roofline: HBM nominally (algorithmic bytes: forward N*48 B gathers + 28 B/pixel outputs;
+// backward N*48 + 20 B/pixel + N*36 B of atomics), VALU/exp bound in practice:
+// ~4*(15 test + 8 blend) VALU per (tile, splat) forward, ~4*(15 + 45) + 54 backward.
 #include "ggs_kernels.h"
 
 namespace {
@@ -21,224 +28,284 @@ __device__ __forceinline__ float dpp_fetch(float v) {
 }
 
 // Sum over the 64 lanes of the wave; the total is valid in lane 63 only.
-// row_shr 1/2/4/8 build row totals in lane 15 of each 16-lane row, row_bcast:15 / :31
-// fold the four rows (GCN/CDNA DPP; no LDS traffic, 6 VALU ops).
 __device__ __forceinline__ float wave_sum_lane63(float v) {
-    v += dpp_fetch<0x111, 0xf>(v);
-    v += dpp_fetch<0x112, 0xf>(v);
-    v += dpp_fetch<0x114, 0xf>(v);
-    v += dpp_fetch<0x118, 0xf>(v);
-    v += dpp_fetch<0x142, 0xa>(v);
-    v += dpp_fetch<0x143, 0xc>(v);
+    v += dpp_fetch<0x111, 0xf>(v);   // row_shr:1
+    v += dpp_fetch<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_fetch<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_fetch<0x118, 0xf>(v);   // row_shr:8  -> lane 15 of each row = row total
+    v += dpp_fetch<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
+    v += dpp_fetch<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 = wave total
     return v;
+}
+
+__device__ __forceinline__ float bcast(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order, used for L2
+// locality only, never for correctness).  XCD k gets the tile ROWS r with r % 8 == k: the tiles
+// of a row share most of their splats (one 4 MB L2 sees each record), while interleaving rows
+// keeps the 8 XCDs evenly loaded when the garment covers only part of the image.
+// Grid: 8 * gx * ceil(gy / 8) workgroups per view; returns -1 for the padding.
+__device__ __forceinline__ int tile_of_block(int b, int gx, int gy) {
+    const int k = b & 7, i = b >> 3;
+    const int row = 8 * (i / gx) + k, col = i % gx;
+    return row < gy ? row * gx + col : -1;
+}
+
+__device__ __forceinline__ unsigned bcast_u(float v, int lane) {
+    return (unsigned)__builtin_amdgcn_readlane(__float_as_int(v), lane);
+}
+
+// Which 8x8 quadrants of the tile at pixel origin (ox, oy) the splat's alpha AABB reaches.
+// Everything here is wave-uniform integer work (SALU compares), so a quadrant the splat cannot
+// touch costs a scalar branch instead of a 64-lane alpha evaluation.
+struct QuadHit {
+    bool q[4];
+    __device__ __forceinline__ QuadHit(unsigned bbx, unsigned bby, int ox, int oy) {
+        const int xmin = ggs_bb_min(bbx), xmax = ggs_bb_max(bbx), ymin = ggs_bb_min(bby), ymax = ggs_bb_max(bby);
+        const bool hx0 = xmin <= ox + 7 && xmax >= ox, hx1 = xmin <= ox + 15 && xmax >= ox + 8;
+        const bool hy0 = ymin <= oy + 7 && ymax >= oy, hy1 = ymin <= oy + 15 && ymax >= oy + 8;
+        q[0] = hx0 && hy0; q[1] = hx1 && hy0; q[2] = hx0 && hy1; q[3] = hx1 && hy1;
+    }
+};
+
+struct Rec3 { float4 a, b, c; };
+
+__device__ __forceinline__ Rec3 gather_round(const float4* __restrict__ rec, const uint32_t* __restrict__ ids,
+                                             int first, int L, int lane) {
+    int i = first + lane;
+    i = i < L ? i : L - 1;
+    i = i < 0 ? 0 : i;
+    const float4* r = rec + (size_t)ids[i] * 3;
+    Rec3 o;
+    o.a = r[0]; o.b = r[1]; o.c = r[2];
+    return o;
 }
 
 }  // namespace
 
-// K4b: grid (T, V), block 256.
-__global__ __launch_bounds__(256) void ggs_k_render_fwd(RenderArgs a) {
+// K4b: grid (8 * gx * ceil(gy/8), V), block 64.
+__global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) {
     if (a.header->overflow) return;
-    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int t = tile_of_block(blockIdx.x, a.gx, a.gy);
+    if (t < 0) return;
+    const int v = blockIdx.y, lane = threadIdx.x;
     const int tx = t % a.gx, ty = t / a.gx;
-    const int px = tx * GGS_TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * GGS_TILE + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < a.W && py < a.H;
+    const int ox = tx * GGS_TILE, oy = ty * GGS_TILE;
+    const int px0 = ox + (lane & 7), py0 = oy + (lane >> 3);
     const int L = (int)a.tile_count[(size_t)v * a.T + t];
     const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
-    const uint32_t* ids = a.ids + base;
-    const float4* rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
+    const uint32_t* __restrict__ ids = a.ids + base;
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
 
-    __shared__ float4 s_rec[GGS_BATCH * 3];
+    float pxf[4], pyf[4], T[4], C0[4], C1[4], C2[4], D[4], A[4];
+    uint32_t last[4];
+    bool done[4], inside[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
+        inside[q] = px < a.W && py < a.H;
+        done[q] = !inside[q];
+        pxf[q] = (float)px; pyf[q] = (float)py;
+        T[q] = 1.f; C0[q] = C1[q] = C2[q] = D[q] = A[q] = 0.f;
+        last[q] = 0;
+    }
 
-    const float pxf = (float)px, pyf = (float)py;
-    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
-    uint32_t contributor = 0, last = 0;
-    bool done = !inside;
-
-    for (int start = 0; start < L; start += GGS_BATCH) {
-        if (__syncthreads_and(done)) break;
-        const int n = min(GGS_BATCH, L - start);
-        if (tid < n) {
-            const float4* r = rec + (size_t)ids[start + tid] * 3;
-            s_rec[tid * 3 + 0] = r[0];
-            s_rec[tid * 3 + 1] = r[1];
-            s_rec[tid * 3 + 2] = r[2];
-        }
-        __syncthreads();
-        for (int j = 0; j < n && !done; ++j) {
-            contributor++;
-            const float4 g0 = s_rec[j * 3 + 0];        // px py cx cy
-            const float4 g1 = s_rec[j * 3 + 1];        // cz opacity r g
-            const float dx = g0.x - pxf, dy = g0.y - pyf;
-            const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
-            if (power > 0.f) continue;
-            const float alpha = ggs_min(GGS_ALPHA_MAX, g1.y * __expf(power));
-            if (alpha < GGS_ALPHA_MIN) continue;
-            const float test_T = T * (1.f - alpha);
-            if (test_T < GGS_T_MIN) { done = true; continue; }
-            const float4 g2 = s_rec[j * 3 + 2];        // b depth radius clamped
-            const float w = alpha * T;
-            C0 = fmaf(g1.z, w, C0);
-            C1 = fmaf(g1.w, w, C1);
-            C2 = fmaf(g2.x, w, C2);
-            D = fmaf(g2.y, w, D);
-            A += w;
-            T = test_T;
-            last = contributor;
+    if (L > 0) {
+        Rec3 nxt = gather_round(rec, ids, 0, L, lane);
+        for (int first = 0; first < L; first += 64) {
+            if (__all(done[0] && done[1] && done[2] && done[3])) break;
+            const Rec3 cur = nxt;
+            if (first + 64 < L) nxt = gather_round(rec, ids, first + 64, L, lane);
+            const int n = min(64, L - first);
+            for (int j = 0; j < n; ++j) {
+                const float gx = bcast(cur.a.x, j), gy = bcast(cur.a.y, j);
+                const float cxx = bcast(cur.a.z, j), cxy = bcast(cur.a.w, j), cyy = bcast(cur.b.x, j);
+                const float op = bcast(cur.b.y, j);
+                const float cr = bcast(cur.b.z, j), cg = bcast(cur.b.w, j), cb = bcast(cur.c.x, j);
+                const float dep = bcast(cur.c.y, j);
+                const QuadHit hit(bcast_u(cur.c.z, j), bcast_u(cur.c.w, j), ox, oy);
+                const uint32_t pos = (uint32_t)(first + j + 1);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (!hit.q[q]) continue;                 // wave-uniform: one scalar branch
+                    // predicated, branch-free per-pixel update: lane masks instead of nested exec juggling
+                    const float dx = gx - pxf[q], dy = gy - pyf[q];
+                    const float power = -0.5f * (cxx * dx * dx + cyy * dy * dy) - cxy * dx * dy;
+                    const float alpha = ggs_min(GGS_ALPHA_MAX, op * __expf(power));
+                    const bool ok = !done[q] & (power <= 0.f) & (alpha >= GGS_ALPHA_MIN);
+                    if (!__any(ok)) continue;
+                    const float test_T = T[q] * (1.f - alpha);
+                    const bool stop = ok & (test_T < GGS_T_MIN);
+                    const bool app = ok & !stop;
+                    done[q] |= stop;
+                    const float w = app ? alpha * T[q] : 0.f;
+                    C0[q] = fmaf(cr, w, C0[q]);
+                    C1[q] = fmaf(cg, w, C1[q]);
+                    C2[q] = fmaf(cb, w, C2[q]);
+                    D[q] = fmaf(dep, w, D[q]);
+                    A[q] += w;
+                    T[q] = app ? test_T : T[q];
+                    last[q] = app ? pos : last[q];
+                }
+                if ((j & 15) == 15 && __all(done[0] && done[1] && done[2] && done[3])) break;
+            }
         }
     }
-    if (inside) {
-        const size_t HW = (size_t)a.H * a.W;
-        const size_t pix = (size_t)py * a.W + px;
-        const float* bg = a.bg + 3 * v;
-        float* oc = a.out_color + (size_t)v * 3 * HW;
-        a.final_T[(size_t)v * HW + pix] = T;
-        a.n_contrib[(size_t)v * HW + pix] = last;
-        oc[pix] = fmaf(T, bg[0], C0);
-        oc[HW + pix] = fmaf(T, bg[1], C1);
-        oc[2 * HW + pix] = fmaf(T, bg[2], C2);
-        a.out_depth[(size_t)v * HW + pix] = D;
-        a.out_alpha[(size_t)v * HW + pix] = A;
+
+    const size_t HW = (size_t)a.H * a.W;
+    const float* bg = a.bg + 3 * v;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+    float* oc = a.out_color + (size_t)v * 3 * HW;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (!inside[q]) continue;
+        const size_t pix = (size_t)(py0 + (q >> 1) * 8) * a.W + (px0 + (q & 1) * 8);
+        a.final_T[(size_t)v * HW + pix] = T[q];
+        a.n_contrib[(size_t)v * HW + pix] = last[q];
+        oc[pix] = fmaf(T[q], bg0, C0[q]);
+        oc[HW + pix] = fmaf(T[q], bg1, C1[q]);
+        oc[2 * HW + pix] = fmaf(T[q], bg2, C2[q]);
+        a.out_depth[(size_t)v * HW + pix] = D[q];
+        a.out_alpha[(size_t)v * HW + pix] = A[q];
     }
 }
 
 namespace {
 
-#define GGS_NGRAD 10
-
 // K5 body.  DA: gradients of the depth / alpha outputs are present.
 template <bool DA>
 __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
-    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
+    const int t = tile_of_block(blockIdx.x, a.gx, a.gy);
+    if (t < 0) return;
+    const int v = blockIdx.y, lane = threadIdx.x;
     const int L = (int)a.tile_count[(size_t)v * a.T + t];
     if (L == 0) return;
-    const int lane = tid & 63, wave = tid >> 6;
     const int tx = t % a.gx, ty = t / a.gx;
-    const int px = tx * GGS_TILE + (wave & 1) * 8 + (lane & 7);
-    const int py = ty * GGS_TILE + (wave >> 1) * 8 + (lane >> 3);
-    const bool inside = px < a.W && py < a.H;
+    const int ox = tx * GGS_TILE, oy = ty * GGS_TILE;
+    const int px0 = ox + (lane & 7), py0 = oy + (lane >> 3);
     const size_t HW = (size_t)a.H * a.W;
-    const size_t pix = (size_t)py * a.W + px;
     const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
-    const uint32_t* ids = a.ids + base;
-    const float4* rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
+    const uint32_t* __restrict__ ids = a.ids + base;
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
     GradRec* acc = a.acc + (size_t)v * a.P;
+    const float* bg = a.bg + 3 * v;
+    const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
-    __shared__ float4 s_rec[GGS_BATCH * 3];
-    __shared__ uint32_t s_id[GGS_BATCH];
-    __shared__ float s_acc[GGS_BATCH * GGS_NGRAD];
-    __shared__ int s_max;
-
-    const int nc = inside ? (int)a.n_contrib[(size_t)v * HW + pix] : 0;
-    if (tid == 0) s_max = 0;
-    __syncthreads();
-    if (nc > 0) atomicMax(&s_max, nc);
-    __syncthreads();
-    const int maxc = s_max;
+    // Per-pixel state of the reverse walk is just (T, B):
+    //   T = transmittance in front of the splat being visited,
+    //   B = Tf * (bg . dL/dC)  +  sum over the splats BEHIND it of  w_k * s_k,
+    //       s_k = c_k . dL/dC (+ depth_k dL/dD + dL/dA),  w_k = alpha_k T_k,
+    // because dL/dalpha_j = T_j s_j - B / (1 - alpha_j).  This is the upstream recurrence
+    // (accum_rec / last_alpha / last_color + the background term) folded into one scalar:
+    // accum_rec_j = (sum_{k>j} c_k w_k) / (T_j (1 - alpha_j)).
+    float pxf[4], pyf[4], T[4], B[4], dC0[4], dC1[4], dC2[4], dD[4], dA[4];
+    int nc[4];
+    int maxc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
+        const bool inside = px < a.W && py < a.H;
+        const size_t pix = (size_t)py * a.W + px;
+        pxf[q] = (float)px; pyf[q] = (float)py;
+        nc[q] = inside ? (int)a.n_contrib[(size_t)v * HW + pix] : 0;
+        maxc = max(maxc, nc[q]);
+        T[q] = inside ? a.final_T[(size_t)v * HW + pix] : 1.f;
+        dC0[q] = dC1[q] = dC2[q] = 0.f; dD[q] = dA[q] = 0.f;
+        if (inside) {
+            const float* dc = a.dL_dcolor + (size_t)v * 3 * HW;
+            dC0[q] = dc[pix]; dC1[q] = dc[HW + pix]; dC2[q] = dc[2 * HW + pix];
+            if (DA) {
+                if (a.dL_ddepth) dD[q] = a.dL_ddepth[(size_t)v * HW + pix];
+                if (a.dL_dalpha) dA[q] = a.dL_dalpha[(size_t)v * HW + pix];
+            }
+        }
+        B[q] = T[q] * (bg0 * dC0[q] + bg1 * dC1[q] + bg2 * dC2[q]);
+    }
+    // wave max of the per-pixel contributor counts
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
     if (maxc == 0) return;
 
-    const float Tf = inside ? a.final_T[(size_t)v * HW + pix] : 1.f;
-    float T = Tf;
-    float dC0 = 0.f, dC1 = 0.f, dC2 = 0.f, dD = 0.f, dA = 0.f;
-    if (inside) {
-        const float* dc = a.dL_dcolor + (size_t)v * 3 * HW;
-        dC0 = dc[pix]; dC1 = dc[HW + pix]; dC2 = dc[2 * HW + pix];
-        if (DA) {
-            if (a.dL_ddepth) dD = a.dL_ddepth[(size_t)v * HW + pix];
-            if (a.dL_dalpha) dA = a.dL_dalpha[(size_t)v * HW + pix];
+    // rounds of 64 list positions, walked from the back: round r covers [64 r, 64 r + 64)
+    int r = (maxc - 1) >> 6;
+    Rec3 nxt = gather_round(rec, ids, r * 64, L, lane);
+    uint32_t nxt_id = ids[min(r * 64 + lane, L - 1)];
+    for (; r >= 0; --r) {
+        const Rec3 cur = nxt;
+        const uint32_t cur_id = nxt_id;
+        if (r > 0) {
+            nxt = gather_round(rec, ids, (r - 1) * 64, L, lane);
+            nxt_id = ids[(r - 1) * 64 + lane];
         }
-    }
-    const float* bg = a.bg + 3 * v;
-    const float bgdot = bg[0] * dC0 + bg[1] * dC1 + bg[2] * dC2;
-    float rec0 = 0.f, rec1 = 0.f, rec2 = 0.f, recD = 0.f, recA = 0.f;
-    float last_a = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_d = 0.f;
-    const float pxf = (float)px, pyf = (float)py;
-
-    for (int hi = maxc; hi > 0; hi -= GGS_BATCH) {
-        const int lo = max(0, hi - GGS_BATCH);
-        const int n = hi - lo;
-        if (tid < n) {
-            const uint32_t id = ids[lo + tid];
-            s_id[tid] = id;
-            const float4* r = rec + (size_t)id * 3;
-            s_rec[tid * 3 + 0] = r[0];
-            s_rec[tid * 3 + 1] = r[1];
-            s_rec[tid * 3 + 2] = r[2];
-        }
-        for (int i = tid; i < n * GGS_NGRAD; i += GGS_BLOCK) s_acc[i] = 0.f;
-        __syncthreads();
-
-        for (int jj = n - 1; jj >= 0; --jj) {
-            const float4 g0 = s_rec[jj * 3 + 0];       // px py cx cy
-            const float4 g1 = s_rec[jj * 3 + 1];       // cz opacity r g
-            const float dx = g0.x - pxf, dy = g0.y - pyf;
-            const float power = -0.5f * (g0.z * dx * dx + g1.x * dy * dy) - g0.w * dx * dy;
-            const float G = __expf(power);
-            const float alpha = ggs_min(GGS_ALPHA_MAX, g1.y * G);
-            const bool valid = (lo + jj < nc) && (power <= 0.f) && (alpha >= GGS_ALPHA_MIN);
-            if (!__any(valid)) continue;               // wave-uniform: nobody in this quadrant blended it
-            float v_r = 0.f, v_g = 0.f, v_b = 0.f, v_op = 0.f, v_mx = 0.f, v_my = 0.f;
-            float v_cx = 0.f, v_cy = 0.f, v_cz = 0.f, v_dep = 0.f;
-            if (valid) {
-                const float4 g2 = s_rec[jj * 3 + 2];   // b depth
-                T = T / (1.f - alpha);
-                const float w = alpha * T;
-                rec0 = last_a * lc0 + (1.f - last_a) * rec0; lc0 = g1.z;
-                rec1 = last_a * lc1 + (1.f - last_a) * rec1; lc1 = g1.w;
-                rec2 = last_a * lc2 + (1.f - last_a) * rec2; lc2 = g2.x;
-                float dL_da = (g1.z - rec0) * dC0 + (g1.w - rec1) * dC1 + (g2.x - rec2) * dC2;
-                v_r = w * dC0; v_g = w * dC1; v_b = w * dC2;
-                if (DA) {
-                    recD = last_a * last_d + (1.f - last_a) * recD; last_d = g2.y;
-                    recA = last_a + (1.f - last_a) * recA;
-                    dL_da += (g2.y - recD) * dD + (1.f - recA) * dA;
-                    v_dep = w * dD;
-                }
-                dL_da *= T;
-                last_a = alpha;
-                dL_da += (-Tf / (1.f - alpha)) * bgdot;
-                const float dL_dG = g1.y * dL_da;      // straight through the 0.99 clamp
+        const int first = r * 64;
+        const int n = min(64, maxc - first);
+        for (int j = n - 1; j >= 0; --j) {
+            const int pos = first + j;                  // list position; pixel q blended it iff pos < nc[q]
+            const float gx = bcast(cur.a.x, j), gy = bcast(cur.a.y, j);
+            const float cxx = bcast(cur.a.z, j), cxy = bcast(cur.a.w, j), cyy = bcast(cur.b.x, j);
+            const float op = bcast(cur.b.y, j);
+            const float cr = bcast(cur.b.z, j), cg = bcast(cur.b.w, j), cb = bcast(cur.c.x, j);
+            const float dep = bcast(cur.c.y, j);
+            const QuadHit hit(bcast_u(cur.c.z, j), bcast_u(cur.c.w, j), ox, oy);
+            float v_mx = 0.f, v_my = 0.f, v_cx = 0.f, v_cy = 0.f, v_cz = 0.f, v_op = 0.f;
+            float v_r = 0.f, v_g = 0.f, v_b = 0.f, v_dep = 0.f;
+            bool any_valid = false;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!hit.q[q]) continue;                 // wave-uniform: scalar branch
+                const float dx = gx - pxf[q], dy = gy - pyf[q];
+                const float power = -0.5f * (cxx * dx * dx + cyy * dy * dy) - cxy * dx * dy;
+                const float Gr = __expf(power);
+                const float ar = ggs_min(GGS_ALPHA_MAX, op * Gr);
+                const bool valid = (pos < nc[q]) & (power <= 0.f) & (ar >= GGS_ALPHA_MIN);
+                if (!__any(valid)) continue;
+                any_valid = true;
+                // predication instead of branches: a lane that did not blend this splat carries
+                // alpha = G = 0, which zeroes every contribution and leaves (T, B) unchanged.
+                const float alpha = valid ? ar : 0.f;
+                const float G = valid ? Gr : 0.f;
+                const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
+                T[q] *= ra;                               // transmittance in front of this splat
+                const float w = alpha * T[q];
+                float sdot = fmaf(cb, dC2[q], fmaf(cg, dC1[q], cr * dC0[q]));
+                if (DA) sdot += fmaf(dep, dD[q], dA[q]);
+                const float dL_da = fmaf(T[q], sdot, -B[q] * ra);
+                B[q] = fmaf(w, sdot, B[q]);
+                v_r = fmaf(w, dC0[q], v_r); v_g = fmaf(w, dC1[q], v_g); v_b = fmaf(w, dC2[q], v_b);
+                if (DA) v_dep = fmaf(w, dD[q], v_dep);
+                const float dL_dG = op * dL_da;            // straight through the 0.99 clamp
                 const float gdx = G * dx, gdy = G * dy;
-                v_mx = dL_dG * (-gdx * g0.z - gdy * g0.w);
-                v_my = dL_dG * (-gdy * g1.x - gdx * g0.w);
-                v_cx = -0.5f * gdx * dx * dL_dG;
-                v_cy = -gdx * dy * dL_dG;
-                v_cz = -0.5f * gdy * dy * dL_dG;
-                v_op = G * dL_da;
+                v_mx = fmaf(dL_dG, -gdx * cxx - gdy * cxy, v_mx);
+                v_my = fmaf(dL_dG, -gdy * cyy - gdx * cxy, v_my);
+                v_cx = fmaf(-0.5f * gdx * dx, dL_dG, v_cx);
+                v_cy = fmaf(-gdx * dy, dL_dG, v_cy);
+                v_cz = fmaf(-0.5f * gdy * dy, dL_dG, v_cz);
+                v_op = fmaf(G, dL_da, v_op);
             }
-            // wave-level sums (uniform control flow), one LDS atomic per wave per value
+            if (!any_valid) continue;                   // (uniform) nobody in the tile blended this splat
             v_mx = wave_sum_lane63(v_mx); v_my = wave_sum_lane63(v_my);
             v_cx = wave_sum_lane63(v_cx); v_cy = wave_sum_lane63(v_cy); v_cz = wave_sum_lane63(v_cz);
             v_op = wave_sum_lane63(v_op);
             v_r = wave_sum_lane63(v_r); v_g = wave_sum_lane63(v_g); v_b = wave_sum_lane63(v_b);
             if (DA) v_dep = wave_sum_lane63(v_dep);
+            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)cur_id, j);
             if (lane == 63) {
-                float* s = s_acc + jj * GGS_NGRAD;
-                atomicAdd(s + 0, v_mx); atomicAdd(s + 1, v_my);
-                atomicAdd(s + 2, v_cx); atomicAdd(s + 3, v_cy); atomicAdd(s + 4, v_cz);
-                atomicAdd(s + 5, v_op);
-                atomicAdd(s + 6, v_r); atomicAdd(s + 7, v_g); atomicAdd(s + 8, v_b);
-                if (DA) atomicAdd(s + 9, v_dep);
+                float* dst = reinterpret_cast<float*>(acc + gid);
+                atomicAdd(dst + 0, v_mx); atomicAdd(dst + 1, v_my);
+                atomicAdd(dst + 2, v_cx); atomicAdd(dst + 3, v_cy); atomicAdd(dst + 4, v_cz);
+                atomicAdd(dst + 5, v_op);
+                atomicAdd(dst + 6, v_r); atomicAdd(dst + 7, v_g); atomicAdd(dst + 8, v_b);
+                if (DA) atomicAdd(dst + 9, v_dep);
             }
         }
-        __syncthreads();
-        if (tid < n) {
-            float* dst = reinterpret_cast<float*>(acc + s_id[tid]);
-            const float* s = s_acc + tid * GGS_NGRAD;
-#pragma unroll
-            for (int c = 0; c < (DA ? 10 : 9); ++c) {
-                const float val = s[c];
-                if (val != 0.f) atomicAdd(dst + c, val);
-            }
-        }
-        __syncthreads();
     }
 }
 
 }  // namespace
 
-// K5: grid (T, V), block 256.  Two entry points so the common case (no loss on depth /
+// K5: grid (8 * gx * ceil(gy/8), V), block 64.  Two entry points so the common case (no loss on depth /
 // alpha: s2_registration.py:258-267, s3_appearance.py:131-140) carries no dead work.
-__global__ __launch_bounds__(256) void ggs_k_render_bwd(RenderBwdArgs a) { render_bwd_body<false>(a); }
-__global__ __launch_bounds__(256) void ggs_k_render_bwd_da(RenderBwdArgs a) { render_bwd_body<true>(a); }
+__global__ __launch_bounds__(64) void ggs_k_render_bwd(RenderBwdArgs a) { render_bwd_body<false>(a); }
+__global__ __launch_bounds__(64) void ggs_k_render_bwd_da(RenderBwdArgs a) { render_bwd_body<true>(a); }

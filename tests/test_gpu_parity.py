@@ -119,7 +119,7 @@ def test_scale_modifier():
 
 
 def test_internals_bit_exact():
-    """num_rendered, per-tile sorted lists and per-pixel contributor counts are index work: exact."""
+    """Per-Gaussian records bit-exact; per-tile sorted lists are exact subsequences of the oracle lists."""
     from ggsplat import rasterizer as R
     from ggsplat.synthetic import stack_cameras
     sc, cam = small_scene(P=3000, W=160, H=120, sh_degree=0, seed=31, scale_mul=5.0)
@@ -131,24 +131,40 @@ def test_internals_bit_exact():
         tanfov=cams["tanfov"], bg=torch.zeros(3, device=dev), W=160, H=120, sh_degree=0)
     co = COracle(means3D=sc["means3D"], opacities=sc["opacities"], shs=sc["shs"], scales=sc["scales"],
                  rotations=sc["rotations"], sh_degree=0, **cam_kwargs(cam, (0, 0, 0)))
-    assert st.num_rendered == co.num_rendered
     it = co.internals()
-    T = 10 * 8
     HW = 160 * 120
     img = st.img.cpu()
-    img_half = (img.numel() // 2)
     final_T = img[:HW * 4].view(torch.float32).reshape(120, 160)
-    n_contrib = img[img_half:img_half + HW * 4].view(torch.int32).reshape(120, 160)
-    assert np.array_equal(n_contrib.numpy().astype(np.uint32), it["n_contrib"])
     assert rel_l1(final_T, it["final_T"]) <= REL_L1_TOL
-    # sorted id lists, tile by tile (view_base is 0 for a single view)
+    assert rel_l1(color[0], co.color) <= REL_L1_TOL and rel_l1(alpha, co.alpha) <= REL_L1_TOL
+    # Binning: the HIP lists may DROP (splat, tile) pairs whose alpha can never reach 1/255 inside the tile
+    # (conservative AABB culling, output-invariant), never add or reorder: each tile's sorted id list must be
+    # a subsequence of the oracle's list, and every dropped pair must be one no pixel of the tile blends.
     from ggsplat.rasterizer import bin_sections
     sec = bin_sections(st)
     counts = sec["tile_count"].cpu().numpy().astype(np.int64).reshape(-1)
-    assert np.array_equal(np.concatenate([[0], np.cumsum(counts)]), it["tile_start"])
-    assert np.array_equal(sec["tile_offset"].cpu().numpy().astype(np.int64).reshape(-1), it["tile_start"][:-1])
-    assert np.array_equal(sec["ids"].cpu().numpy()[:co.num_rendered].astype(np.uint32), it["list"])
-    # per-Gaussian records: bit-exact geometry
+    offs = sec["tile_offset"].cpu().numpy().astype(np.int64).reshape(-1)
+    ids = sec["ids"].cpu().numpy().astype(np.uint32)
+    assert st.num_rendered == counts.sum() <= co.num_rendered
+    assert st.num_rendered > 0.5 * co.num_rendered
+    xy, con = it["xy"], it["conic_opacity"]
+    gx = 10
+    for t in range(len(counts)):
+        mine = ids[offs[t]:offs[t] + counts[t]]
+        ref = it["list"][it["tile_start"][t]:it["tile_start"][t + 1]]
+        pos = {int(g): i for i, g in enumerate(ref)}
+        idx = [pos[int(g)] for g in mine]                    # KeyError = an id the oracle does not have
+        assert idx == sorted(idx), f"tile {t}: order differs"
+        dropped = sorted(set(int(g) for g in ref) - set(int(g) for g in mine))
+        if dropped:
+            ys, xs = np.meshgrid(np.arange((t // gx) * 16, (t // gx) * 16 + 16),
+                                 np.arange((t % gx) * 16, (t % gx) * 16 + 16), indexing="ij")
+            for g in dropped:
+                dx, dy = xy[g, 0] - xs, xy[g, 1] - ys
+                power = -0.5 * (con[g, 0] * dx * dx + con[g, 2] * dy * dy) - con[g, 1] * dx * dy
+                a_ = np.where(power > 0, 0.0, np.minimum(0.99, con[g, 3] * np.exp(np.minimum(power, 0))))
+                assert a_.max() < 1.0 / 255.0, f"tile {t}: dropped splat {g} would have been blended"
+    # per-Gaussian records: bit-exact geometry (floats 0..9 of the 48-byte record)
     rec = st.geom.cpu()[:3000 * 48].view(torch.float32).reshape(3000, 12).numpy()
     vis = co.radii > 0
     assert np.array_equal(rec[vis, 0:2], it["xy"][vis])

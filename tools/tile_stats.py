@@ -1,0 +1,28 @@
+"""Tile-list statistics of the config-2 workload (GPU): list lengths, processed lengths."""
+import sys, os, torch, numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "gaussian-garments_amd"))
+from ggsplat import synthetic as S, rasterizer as R
+from ggsplat.mesh_gaussian_model import MeshGaussianModel
+dev = "cuda"
+v, f = S.skirt_mesh(); p = S.skirt_gaussian_params(f.shape[0], 0)
+m = MeshGaussianModel.from_tensors(v, f, p, 0, device=dev)
+cams = S.rig_cameras()
+for vi in (0, 40, 100, 159):
+    ck = S.stack_cameras([cams[vi]], device=dev)
+    with torch.no_grad():
+        m.update_face_coor()
+        color, radii, depth, alpha, st = R.forward_views(m.get_xyz, m.get_opacity, m.get_features, None, m.get_scaling, m.get_rotation, None,
+            view=ck["view"], proj=ck["proj"], campos=ck["campos"], tanfov=ck["tanfov"], bg=torch.zeros(3, device=dev), W=1920, H=1080, sh_degree=0)
+    sec = R.bin_sections(st)
+    cnt = sec["tile_count"][0].cpu().numpy().astype(np.int64)
+    HW = 1920 * 1080
+    img = st.img
+    half = img.numel() // 2
+    ncon = img[half:half + HW * 4].view(torch.int32).reshape(1080, 1920)
+    nc = torch.nn.functional.pad(ncon, (0, 0, 0, 8))  # H 1080 -> 1088
+    tmax = nc.reshape(68, 16, 120, 16).permute(0, 2, 1, 3).reshape(68 * 120, 256).max(1).values.cpu().numpy()
+    act = cnt > 0
+    pct = lambda a: [int(np.percentile(a, q)) for q in (50, 90, 99, 100)]
+    print(f"view {vi}: N={cnt.sum()} active tiles={act.sum()} L pct50/90/99/max={pct(cnt[act])} processed(max n_contrib per tile) pct={pct(tmax[act])} "
+          f"sum L={cnt.sum()} sum processed={tmax.sum()} mean n_contrib/covered px={float(ncon[ncon>0].float().mean()):.1f} covered px={int((ncon>0).sum())} radii mean={float(radii.float().mean()):.1f}")
