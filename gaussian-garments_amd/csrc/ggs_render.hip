@@ -27,14 +27,32 @@ __device__ __forceinline__ float dpp_fetch(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
 }
 
-// Sum over the 64 lanes of the wave; the total is valid in lane 63 only.
-__device__ __forceinline__ float wave_sum_lane63(float v) {
+// ---- wave reduction of the 10 per-splat gradient values ----------------------------------------
+// gfx950 has v_permlane32_swap / v_permlane16_swap: exchanging halves (rows) between TWO registers
+// and adding folds two values at once, so the 64-lane sums of 10 values cost 28 VALU ops instead of
+// 10 x 8 with one DPP chain per value:
+//   swap32_add(x, y)   -> lanes 0-31: 32 partials of x        | lanes 32-63: 32 partials of y
+//   swap16_add(z1, z2) -> rows 0..3 (16 lanes each): partials of (z1.lo, z2.lo, z1.hi, z2.hi)
+//   row_sum_lane15     -> lane 15 of every row = that row's total (4 DPP row_shr adds)
+__device__ __forceinline__ float swap32_add(float x, float y) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap16_add(float z1, float z2) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(z1), __float_as_uint(z2), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float row_sum_lane15(float v) {
     v += dpp_fetch<0x111, 0xf>(v);   // row_shr:1
     v += dpp_fetch<0x112, 0xf>(v);   // row_shr:2
     v += dpp_fetch<0x114, 0xf>(v);   // row_shr:4
     v += dpp_fetch<0x118, 0xf>(v);   // row_shr:8  -> lane 15 of each row = row total
+    return v;
+}
+// two values in the two 32-lane halves -> totals in lanes 31 and 63
+__device__ __forceinline__ float half_sum_lane31_63(float v) {
+    v = row_sum_lane15(v);
     v += dpp_fetch<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    v += dpp_fetch<0x143, 0xc>(v);   // row_bcast:31 into rows 2 and 3 -> lane 63 = wave total
     return v;
 }
 
@@ -223,6 +241,10 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
         }
         B[q] = T[q] * (bg0 * dC0[q] + bg1 * dC1[q] + bg2 * dC2[q]);
     }
+    // GradRec field written by this lane after the reduction: row r of 16 lanes ends up with field
+    // pair-index ((r & 1) << 1) | (r >> 1) of {mx,my,cx,cy} (and of {cz,op,r,g} at +4)
+    const int row = lane >> 4;
+    const int fld = ((row & 1) << 1) | (row >> 1);
     // wave max of the per-pixel contributor counts
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
@@ -285,19 +307,16 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
                 v_op = fmaf(G, dL_da, v_op);
             }
             if (!any_valid) continue;                   // (uniform) nobody in the tile blended this splat
-            v_mx = wave_sum_lane63(v_mx); v_my = wave_sum_lane63(v_my);
-            v_cx = wave_sum_lane63(v_cx); v_cy = wave_sum_lane63(v_cy); v_cz = wave_sum_lane63(v_cz);
-            v_op = wave_sum_lane63(v_op);
-            v_r = wave_sum_lane63(v_r); v_g = wave_sum_lane63(v_g); v_b = wave_sum_lane63(v_b);
-            if (DA) v_dep = wave_sum_lane63(v_dep);
+            // totals land in: S1 lanes 15/31/47/63 = (mx, cx, my, cy); S2 = (cz, r, op, g); S3 lanes 31/63 = (b, depth)
+            const float S1 = row_sum_lane15(swap16_add(swap32_add(v_mx, v_my), swap32_add(v_cx, v_cy)));
+            const float S2 = row_sum_lane15(swap16_add(swap32_add(v_cz, v_op), swap32_add(v_r, v_g)));
+            const float S3 = half_sum_lane31_63(swap32_add(v_b, v_dep));
             const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)cur_id, j);
-            if (lane == 63) {
-                float* dst = reinterpret_cast<float*>(acc + gid);
-                atomicAdd(dst + 0, v_mx); atomicAdd(dst + 1, v_my);
-                atomicAdd(dst + 2, v_cx); atomicAdd(dst + 3, v_cy); atomicAdd(dst + 4, v_cz);
-                atomicAdd(dst + 5, v_op);
-                atomicAdd(dst + 6, v_r); atomicAdd(dst + 7, v_g); atomicAdd(dst + 8, v_b);
-                if (DA) atomicAdd(dst + 9, v_dep);
+            float* dst = reinterpret_cast<float*>(acc + gid);
+            if ((lane & 15) == 15) {                         // 4 lanes issue 4 atomics per instruction
+                atomicAdd(dst + fld, S1);
+                atomicAdd(dst + 4 + fld, S2);
+                if ((row & 1) && (DA || row == 1)) atomicAdd(dst + 8 + (row >> 1), S3);
             }
         }
     }
