@@ -29,14 +29,43 @@ __device__ __forceinline__ void sh_to_rgb(const float* __restrict__ sh, const fl
     }
 }
 
+// ---- block-aggregated tile histogram ---------------------------------------------------------
+// The 256 splats of a workgroup are neighbours on the garment mesh, so together they touch a
+// small window of tiles.  Instead of one global atomic per (splat, tile) instance (hundreds of
+// increments on the same few counters), the instances are first counted in a dense LDS array
+// over the workgroup's tile window (ds_add), and ONE global atomic per touched tile and
+// workgroup carries the sum.  Falls back to direct global atomics if the window is too large.
+#define BIN_WINDOW_CAP 2048
+
+struct TileWindow { int x0, y0, w, h; bool dense; };
+
+__device__ __forceinline__ TileWindow block_tile_window(int* s_box, bool has, int x0, int y0, int x1, int y1) {
+    if (threadIdx.x == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -0x7fffffff; s_box[3] = -0x7fffffff; }
+    __syncthreads();
+    if (has) {
+        atomicMin(&s_box[0], x0); atomicMin(&s_box[1], y0);
+        atomicMax(&s_box[2], x1); atomicMax(&s_box[3], y1);
+    }
+    __syncthreads();
+    TileWindow w;
+    w.x0 = s_box[0]; w.y0 = s_box[1];
+    w.w = s_box[2] - s_box[0]; w.h = s_box[3] - s_box[1];
+    w.dense = w.w > 0 && w.h > 0 && (long long)w.w * w.h <= BIN_WINDOW_CAP;
+    if (w.w <= 0 || w.h <= 0) { w.w = 0; w.h = 0; }
+    return w;
+}
+
 }  // namespace
 
 // K1: grid (ceil(P/256), V).  Writes SplatRec + radii, and counts tiles per splat into
 // tile_count[v][t] (cleared by the caller's memset).
 __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
+    __shared__ int s_box[4];
+    __shared__ uint32_t s_cnt[BIN_WINDOW_CAP];
+    const int g0 = blockIdx.x * 256 + threadIdx.x;
+    const bool live = g0 < a.P;
+    const int g = live ? g0 : a.P - 1;           // idle lanes shadow the last splat, write nothing
     const int v = blockIdx.y;
-    if (g >= a.P) return;
     const float* __restrict__ view = a.view + 16 * v;
     const float* __restrict__ proj = a.proj + 16 * v;
     const float tanfovx = a.tanfov[2 * v], tanfovy = a.tanfov[2 * v + 1];
@@ -114,15 +143,34 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
             }
         }
     }
-    a.radii[vg] = radius;
-    SplatAux ax; ax.radius = radius; ax.clamped = clamped;
-    a.aux[vg] = ax;
-    float4* dst = reinterpret_cast<float4*>(rec);
-    const float4* src = reinterpret_cast<const float4*>(&out);
-    dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
-    if (radius > 0) {
+    if (live) {
+        a.radii[vg] = radius;
+        SplatAux ax; ax.radius = radius; ax.clamped = clamped;
+        a.aux[vg] = ax;
+        float4* dst = reinterpret_cast<float4*>(rec);
+        const float4* src = reinterpret_cast<const float4*>(&out);
+        dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2];
+    }
+    bool has = live && radius > 0;
+    if (has) {
         ggs_cull_rect(out.bbx, out.bby, x0, y0, x1, y1);
-        uint32_t* cnt = a.tile_count + (size_t)v * a.T;
+        has = x0 < x1 && y0 < y1;
+    }
+    uint32_t* cnt = a.tile_count + (size_t)v * a.T;
+    const TileWindow w = block_tile_window(s_box, has, x0, y0, x1, y1);
+    if (w.dense) {
+        const int area = w.w * w.h;
+        for (int i = threadIdx.x; i < area; i += 256) s_cnt[i] = 0;
+        __syncthreads();
+        if (has)
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) atomicAdd(&s_cnt[(y - w.y0) * w.w + (x - w.x0)], 1u);
+        __syncthreads();
+        for (int i = threadIdx.x; i < area; i += 256) {
+            const uint32_t c = s_cnt[i];
+            if (c) atomicAdd(&cnt[(w.y0 + i / w.w) * gx + w.x0 + i % w.w], c);
+        }
+    } else if (has) {
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) atomicAdd(&cnt[y * gx + x], 1u);
     }
@@ -133,27 +181,63 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
 // the per-tile sort makes the final order (depth, id) deterministic.
 __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
     if (a.header->overflow) return;
+    __shared__ int s_box[4];
+    __shared__ uint32_t s_cnt[BIN_WINDOW_CAP];
+    __shared__ uint32_t s_base[BIN_WINDOW_CAP];
     const int g = blockIdx.x * 256 + threadIdx.x;
     const int v = blockIdx.y;
-    if (g >= a.P) return;
-    const SplatRec* rec = a.rec + (size_t)v * a.P + g;
-    const float4 r0 = reinterpret_cast<const float4*>(rec)[0];
-    const float4 r2 = reinterpret_cast<const float4*>(rec)[2];
-    const int radius = a.aux[(size_t)v * a.P + g].radius;
-    if (radius <= 0) return;
-    int x0, y0, x1, y1;
-    ggs_tile_rect(r0.x, r0.y, (float)radius, a.gx, a.gy, x0, y0, x1, y1);
-    ggs_cull_rect(__float_as_uint(r2.z), __float_as_uint(r2.w), x0, y0, x1, y1);
-    const unsigned long long key = ((unsigned long long)__float_as_uint(r2.y) << 32) | (unsigned)g;
+    int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
+    unsigned long long key = 0;
+    bool has = false;
+    if (g < a.P) {
+        const int radius = a.aux[(size_t)v * a.P + g].radius;
+        if (radius > 0) {
+            const SplatRec* rec = a.rec + (size_t)v * a.P + g;
+            const float4 r0 = reinterpret_cast<const float4*>(rec)[0];
+            const float4 r2 = reinterpret_cast<const float4*>(rec)[2];
+            ggs_tile_rect(r0.x, r0.y, (float)radius, a.gx, a.gy, x0, y0, x1, y1);
+            ggs_cull_rect(__float_as_uint(r2.z), __float_as_uint(r2.w), x0, y0, x1, y1);
+            key = ((unsigned long long)__float_as_uint(r2.y) << 32) | (unsigned)g;
+            has = x0 < x1 && y0 < y1;
+        }
+    }
     uint32_t* cur = a.tile_cursor + (size_t)v * a.T;
     const uint32_t* off = a.tile_offset + (size_t)v * a.T;
     unsigned long long* keys = a.keys + a.view_base[v];
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) {
-            const int t = y * a.gx + x;
-            const uint32_t slot = atomicAdd(&cur[t], 1u);
-            keys[(size_t)off[t] + slot] = key;
+    const TileWindow w = block_tile_window(s_box, has, x0, y0, x1, y1);
+    if (w.dense) {
+        // count in LDS -> one returning global atomic per touched tile claims the workgroup's run of
+        // slots -> second LDS pass hands out the slots inside the run
+        const int area = w.w * w.h;
+        for (int i = threadIdx.x; i < area; i += 256) s_cnt[i] = 0;
+        __syncthreads();
+        if (has)
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) atomicAdd(&s_cnt[(y - w.y0) * w.w + (x - w.x0)], 1u);
+        __syncthreads();
+        for (int i = threadIdx.x; i < area; i += 256) {
+            const uint32_t c = s_cnt[i];
+            if (c) {
+                const int t = (w.y0 + i / w.w) * a.gx + w.x0 + i % w.w;
+                s_base[i] = off[t] + atomicAdd(&cur[t], c);
+                s_cnt[i] = 0;
+            }
         }
+        __syncthreads();
+        if (has)
+            for (int y = y0; y < y1; ++y)
+                for (int x = x0; x < x1; ++x) {
+                    const int i = (y - w.y0) * w.w + (x - w.x0);
+                    keys[(size_t)s_base[i] + atomicAdd(&s_cnt[i], 1u)] = key;
+                }
+    } else if (has) {
+        for (int y = y0; y < y1; ++y)
+            for (int x = x0; x < x1; ++x) {
+                const int t = y * a.gx + x;
+                const uint32_t slot = atomicAdd(&cur[t], 1u);
+                keys[(size_t)off[t] + slot] = key;
+            }
+    }
 }
 
 namespace {
