@@ -30,7 +30,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
-KERNELS = ["preprocess", "scan_tiles", "scatter", "sort_tiles", "render_fwd", "render_bwd", "preprocess_bwd"]
+KERNELS = ["preprocess", "scan_tiles", "scatter", "sort_tiles", "render_fwd", "render_bwd", "preprocess_bwd", "order_tiles"]
 
 
 def parse():
@@ -153,9 +153,10 @@ def main():
             buf = (C.c_float * 8)()
             L.ggs_profile_read(buf, 8)
             fwd_ms = list(buf)[:5]
+            order_ms = buf[7]
             R.backward_views(st, dL_buf[:chunk], want_means2D=False)
             L.ggs_profile_read(buf, 8)
-            ms = fwd_ms + list(buf)[5:7]
+            ms = fwd_ms + list(buf)[5:7] + [order_ms]
             acc_ms = [a + b for a, b in zip(acc_ms, ms)]
             P_vis = float((radii > 0).sum().item()) / chunk
             N_chunk = st.num_rendered
@@ -166,7 +167,7 @@ def main():
         T = ((W + 15) // 16) * ((H + 15) // 16)
         B = alg_bytes(Fn, K, P_vis, N_view, W * H, T)
         group_ms = {"preprocess": kern_ms["preprocess"],
-                    "binning": kern_ms["scan_tiles"] + kern_ms["scatter"] + kern_ms["sort_tiles"],
+                    "binning": kern_ms["scan_tiles"] + kern_ms["order_tiles"] + kern_ms["scatter"] + kern_ms["sort_tiles"],
                     "render_fwd": kern_ms["render_fwd"], "render_bwd": kern_ms["render_bwd"],
                     "preprocess_bwd": kern_ms["preprocess_bwd"]}
         dom = max(("render_fwd", "render_bwd", "preprocess", "preprocess_bwd"), key=lambda k: group_ms[k])

@@ -27,7 +27,7 @@ namespace {
 #define fail ggs_fail_
 
 // ---- optional per-kernel timing (bench.py roofline leg) ------------------------------------
-enum { K_PRE = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD, K_PRE_BWD, K_COUNT };
+enum { K_PRE = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD, K_PRE_BWD, K_ORDER, K_COUNT };
 struct Profile {
     bool on = false, have = false;
     hipEvent_t ev[K_COUNT][2];
@@ -170,6 +170,10 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
     unsigned long long* view_base = (unsigned long long*)(b + L.view_base);
     unsigned long long* keys = (unsigned long long*)(b + L.keys);
     uint32_t* ids = (uint32_t*)(b + L.ids);
+    uint32_t* order = (uint32_t*)(b + L.order);
+    uint32_t* bucket_count = (uint32_t*)(b + L.header + GGS_BUCKET_COUNT_OFF);
+    uint32_t* bucket_cursor = (uint32_t*)(b + L.header + GGS_BUCKET_CURSOR_OFF);
+    const int n_items = V * d.T;
     const size_t HW = (size_t)p->W * p->H;
     float* final_T = (float*)img;
     uint32_t* n_contrib = (uint32_t*)((char*)img + ggs_align((size_t)V * HW * 4));
@@ -195,11 +199,18 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
     {
         ScanArgs a;
         a.T = d.T; a.capacity = (unsigned long long)bin_capacity; a.tile_count = tile_count;
-        a.tile_offset = tile_offset; a.view_base = view_base; a.header = header;
+        a.tile_offset = tile_offset; a.view_base = view_base; a.header = header; a.bucket_count = bucket_count;
         prof_start(K_SCAN, s);
         hipLaunchKernelGGL(ggs_k_scan_tiles, dim3((unsigned)V), dim3(1024), 0, s, a);
         prof_stop(K_SCAN, s);
         GGS_TRY(check("scan_tiles", s, p->debug));
+        OrderArgs o;
+        o.n_items = n_items; o.tile_count = tile_count; o.bucket_count = bucket_count;
+        o.bucket_cursor = bucket_cursor; o.order = order;
+        prof_start(K_ORDER, s);
+        hipLaunchKernelGGL(ggs_k_order_tiles, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, o);
+        prof_stop(K_ORDER, s);
+        GGS_TRY(check("order_tiles", s, p->debug));
     }
     if (p->P > 0) {
         ScatterArgs a;
@@ -214,21 +225,21 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
     const dim3 gridT((unsigned)d.T, (unsigned)V);
     {
         SortArgs a;
-        a.T = d.T; a.header = header; a.tile_count = tile_count; a.tile_offset = tile_offset;
-        a.view_base = view_base; a.keys = keys; a.ids = ids;
+        a.T = d.T; a.n_items = n_items; a.order = order; a.header = header; a.tile_count = tile_count;
+        a.tile_offset = tile_offset; a.view_base = view_base; a.keys = keys; a.ids = ids;
         prof_start(K_SORT, s);
-        hipLaunchKernelGGL(ggs_k_sort_tiles, gridT, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(ggs_k_sort_tiles, dim3((unsigned)n_items), dim3(256), 0, s, a);
         prof_stop(K_SORT, s);
         GGS_TRY(check("sort_tiles", s, p->debug));
     }
     {
         RenderArgs a;
         a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.header = header;
-        a.tile_count = tile_count; a.tile_offset = tile_offset; a.view_base = view_base; a.ids = ids;
+        a.n_items = n_items; a.order = order; a.tile_count = tile_count; a.tile_offset = tile_offset; a.view_base = view_base; a.ids = ids;
         a.rec = (const SplatRec*)geom; a.bg = bg; a.out_color = out_color; a.out_depth = out_depth;
         a.out_alpha = out_alpha; a.final_T = final_T; a.n_contrib = n_contrib;
         prof_start(K_RENDER_FWD, s);
-        hipLaunchKernelGGL(ggs_k_render_fwd, dim3((unsigned)(8 * d.gx * ((d.gy + 7) / 8)), (unsigned)V), dim3(64), 0, s, a);
+        hipLaunchKernelGGL(ggs_k_render_fwd, dim3((unsigned)n_items), dim3(64), 0, s, a);
         prof_stop(K_RENDER_FWD, s);
         GGS_TRY(check("render_fwd", s, p->debug));
     }
@@ -267,6 +278,7 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
     {
         RenderBwdArgs a;
         a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T;
+        a.n_items = V * d.T; a.order = (const uint32_t*)(b + L.order);
         a.tile_count = (const uint32_t*)(b + L.tile_count);
         a.tile_offset = (const uint32_t*)(b + L.tile_offset);
         a.view_base = (const unsigned long long*)(b + L.view_base);
@@ -276,7 +288,7 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
         a.n_contrib = (const uint32_t*)((const char*)img + ggs_align((size_t)V * HW * 4));
         a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth; a.dL_dalpha = dL_dalpha;
         a.acc = (GradRec*)scratch;
-        const dim3 gridT((unsigned)(8 * d.gx * ((d.gy + 7) / 8)), (unsigned)V);   // one wave64 per tile, tile rows interleaved over XCDs
+        const dim3 gridT((unsigned)(V * d.T));   // one wave64 per (view, tile) work item, longest lists first
         prof_start(K_RENDER_BWD, s);
         if (dL_ddepth || dL_dalpha) hipLaunchKernelGGL(ggs_k_render_bwd_da, gridT, dim3(64), 0, s, a);
         else hipLaunchKernelGGL(ggs_k_render_bwd, gridT, dim3(64), 0, s, a);

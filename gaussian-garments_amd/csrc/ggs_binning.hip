@@ -18,9 +18,16 @@ __global__ __launch_bounds__(1024) void ggs_k_scan_tiles(ScanArgs a) {
     uint32_t* off = a.tile_offset + (size_t)v * a.T;
     const int per = (a.T + 1023) / 1024;
     const int t0 = tid * per;
+    __shared__ uint32_t s_bucket[GGS_NBUCKET];
+    if (tid < GGS_NBUCKET) s_bucket[tid] = 0;
+    __syncthreads();
     uint32_t local = 0;
     for (int i = 0; i < per; ++i)
-        if (t0 + i < a.T) local += cnt[t0 + i];
+        if (t0 + i < a.T) {
+            const uint32_t c = cnt[t0 + i];
+            local += c;
+            atomicAdd(&s_bucket[ggs_len_bucket(c)], 1u);
+        }
     // inclusive scan inside each wave64, then across the 16 waves
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t x = local;
@@ -44,10 +51,52 @@ __global__ __launch_bounds__(1024) void ggs_k_scan_tiles(ScanArgs a) {
             off[t0 + i] = run;
             run += cnt[t0 + i];
         }
+    if (tid < GGS_NBUCKET && s_bucket[tid]) atomicAdd(&a.bucket_count[tid], s_bucket[tid]);
     if (tid == 0) {
         const unsigned long long base = atomicAdd(&a.header->num_rendered, (unsigned long long)total);
         a.view_base[v] = base;
         if (base + total > a.capacity) atomicExch(&a.header->overflow, 1ull);
+    }
+}
+
+// K2b: grid ceil(V*T/256), block 256.  Counting sort of the (view, tile) work items by list-length
+// class (longest first) into order[]; inside a class the order is arbitrary.  Empty tiles (class 7:
+// the forward only writes the background there, HBM-bound) are interleaved evenly between the
+// non-empty ones (ALU-bound) so that the two kinds of work overlap instead of running back to back:
+// with NE non-empty and E empty items and k = E / NE rounded down to even, item slots repeat
+// [1 non-empty, k empty] and the E - k NE left-over empties go last.
+__global__ __launch_bounds__(256) void ggs_k_order_tiles(OrderArgs a) {
+    __shared__ uint32_t s_n[GGS_NBUCKET], s_base[GGS_NBUCKET];
+    const int tid = threadIdx.x;
+    const int i = blockIdx.x * 256 + tid;
+    if (tid < GGS_NBUCKET) s_n[tid] = 0;
+    __syncthreads();
+    int b = 0;
+    uint32_t rank = 0;
+    if (i < a.n_items) {
+        b = ggs_len_bucket(a.tile_count[i]);
+        rank = atomicAdd(&s_n[b], 1u);
+    }
+    __syncthreads();
+    if (tid < GGS_NBUCKET) {
+        uint32_t start = 0;                       // rank of the class among the non-empty items (class 7: 0)
+        if (tid < GGS_NBUCKET - 1)
+            for (int k = 0; k < tid; ++k) start += a.bucket_count[k];
+        s_base[tid] = s_n[tid] ? start + atomicAdd(&a.bucket_cursor[tid], s_n[tid]) : 0;
+    }
+    __syncthreads();
+    if (i < a.n_items) {
+        const uint32_t E = a.bucket_count[GGS_NBUCKET - 1];
+        const uint32_t NE = (uint32_t)a.n_items - E;
+        // k even => period k + 1 odd: workgroup b lands on XCD b % 8 (observed), so an even period would
+        // park all the non-empty tiles on a subset of the 8 XCDs
+        const uint32_t k = NE ? (E / NE) & ~1u : 0;
+        const uint32_t r = s_base[b] + rank;      // rank among non-empty items, or among the empty ones
+        uint32_t pos;
+        if (b != GGS_NBUCKET - 1) pos = r * (k + 1);
+        else if (r < k * NE) pos = (r / k) * (k + 1) + 1 + (r % k);
+        else pos = NE * (k + 1) + (r - k * NE);
+        a.order[pos] = (uint32_t)i;
     }
 }
 
@@ -84,11 +133,12 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr key, int L, int n2, int tid,
 
 }  // namespace
 
-// K4a: grid (T, V), block 256.  Sorts the tile's key segment by (depth bits, id) and
+// K4a: grid V*T (work items in order[]), block 256.  Sorts the tile's key segment by (depth bits, id) and
 // writes the id list the render kernels walk.
 __global__ __launch_bounds__(256) void ggs_k_sort_tiles(SortArgs a) {
     if (a.header->overflow) return;
-    const int t = blockIdx.x, v = blockIdx.y, tid = threadIdx.x;
+    const uint32_t item = a.order[blockIdx.x];
+    const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), tid = threadIdx.x;
     const int L = (int)a.tile_count[(size_t)v * a.T + t];
     if (L == 0) return;
     const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];

@@ -6,7 +6,9 @@
 //                                        from one or two cache lines;
 //          SplatAux aux[V][P]            8 B: radius + SH clamp bits (binning / backward only).
 //   bin  : BinHeader | tile_count[V][T] | tile_cursor[V][T] | tile_offset[V][T] |
-//          view_base[V] | keys[cap] (u64: depth bits << 32 | Gaussian id) | ids[cap] (u32)
+//          view_base[V] | order[V*T] (work items v*T+t, heaviest tile lists first) |
+//          keys[cap] (u64: depth bits << 32 | Gaussian id) | ids[cap] (u32)
+//          (BinHeader bytes 64.. hold the 8 list-length bucket counters / cursors of `order`)
 //   img  : final_T[V][H*W] f32 | n_contrib[V][H*W] u32
 //   bwd scratch : GradRec acc[V][P]      48 B per (view, Gaussian), atomically accumulated
 //                                        per-Gaussian screen-space gradients.
@@ -20,6 +22,9 @@
 #define GGS_BLOCK 256            // threads per render block = one 16x16 tile = 4 wave64
 #define GGS_BATCH 256            // splats staged in LDS per round
 #define GGS_SORT_CAP 4096        // per-tile list length sorted in LDS (above: global fallback)
+#define GGS_NBUCKET 8             // list-length classes used to order the per-tile work items
+#define GGS_BUCKET_COUNT_OFF 64   // byte offsets inside the header region
+#define GGS_BUCKET_CURSOR_OFF 96
 
 // Constants of the algorithm, one line each.
 #define GGS_NEAR_Z 0.2f
@@ -58,7 +63,7 @@ struct GradRec {                 // per-(view, Gaussian) gradient accumulators
 static_assert(sizeof(GradRec) == 48, "GradRec must be 48 bytes");
 
 struct BinLayout {               // byte offsets inside the binning buffer
-    size_t header, tile_count, tile_cursor, tile_offset, view_base, keys, ids, total;
+    size_t header, tile_count, tile_cursor, tile_offset, view_base, order, keys, ids, total;
     size_t zero_bytes;           // header + tile_count + tile_cursor are cleared each forward
 };
 
@@ -73,6 +78,7 @@ static inline BinLayout ggs_bin_layout(int V, int T, size_t cap) {
     L.zero_bytes = o;
     L.tile_offset = o; o += ggs_align((size_t)V * T * 4);
     L.view_base = o;   o += ggs_align((size_t)V * 8);
+    L.order = o;       o += ggs_align((size_t)V * T * 4);
     L.keys = o;        o += ggs_align(cap * 8);
     L.ids = o;         o += ggs_align(cap * 4);
     L.total = o;
@@ -82,6 +88,16 @@ static inline BinLayout ggs_bin_layout(int V, int T, size_t cap) {
 #ifdef __HIPCC__
 __device__ __forceinline__ float ggs_min(float a, float b) { return a < b ? a : b; }
 __device__ __forceinline__ float ggs_max(float a, float b) { return a > b ? a : b; }
+
+// Work-item class of a tile by list length: 0 = longest lists ... 6 = 1..63 splats, 7 = empty.
+// The per-tile kernels walk `order[]` (class 0 first): the longest serial chains start first and the
+// tail of every launch is made of short / empty tiles (LPT scheduling), instead of whatever the last
+// view happens to contain.
+__device__ __forceinline__ int ggs_len_bucket(uint32_t L) {
+    if (L == 0) return 7;
+    const int lg = 31 - __clz((int)L);
+    return lg <= 5 ? 6 : (lg >= 11 ? 0 : 11 - lg);
+}
 
 // Tile rectangle of a splat (A.1 step 6); must be bit-identical wherever it is recomputed.
 __device__ __forceinline__ void ggs_tile_rect(float px, float py, float r, int gx, int gy, int& x0, int& y0,

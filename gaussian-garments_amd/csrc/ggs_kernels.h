@@ -20,6 +20,15 @@ struct ScanArgs {
     uint32_t* tile_offset;
     unsigned long long* view_base;
     GgsBinHeader* header;
+    uint32_t* bucket_count;   // [GGS_NBUCKET]
+};
+
+struct OrderArgs {
+    int n_items;              // V * T
+    const uint32_t* tile_count;
+    const uint32_t* bucket_count;
+    uint32_t* bucket_cursor;
+    uint32_t* order;
 };
 
 struct ScatterArgs {
@@ -34,7 +43,8 @@ struct ScatterArgs {
 };
 
 struct SortArgs {
-    int T;
+    int T, n_items;
+    const uint32_t* order;
     const GgsBinHeader* header;
     const uint32_t* tile_count;
     const uint32_t* tile_offset;
@@ -44,7 +54,8 @@ struct SortArgs {
 };
 
 struct RenderArgs {
-    int P, W, H, gx, gy, T;
+    int P, W, H, gx, gy, T, n_items;
+    const uint32_t* order;
     const GgsBinHeader* header;
     const uint32_t* tile_count;
     const uint32_t* tile_offset;
@@ -60,7 +71,8 @@ struct RenderArgs {
 };
 
 struct RenderBwdArgs {
-    int P, W, H, gx, gy, T;
+    int P, W, H, gx, gy, T, n_items;
+    const uint32_t* order;
     const uint32_t* tile_count;
     const uint32_t* tile_offset;
     const unsigned long long* view_base;
@@ -89,6 +101,7 @@ struct PreBwdArgs {
 __global__ void ggs_k_preprocess(PreArgs a);
 __global__ void ggs_k_scan_tiles(ScanArgs a);
 __global__ void ggs_k_scatter(ScatterArgs a);
+__global__ void ggs_k_order_tiles(OrderArgs a);
 __global__ void ggs_k_sort_tiles(SortArgs a);
 __global__ void ggs_k_render_fwd(RenderArgs a);
 __global__ void ggs_k_render_bwd(RenderBwdArgs a);

@@ -321,7 +321,6 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess_bwd(PreBwdArgs a) {
 
     for (int v = 0; v < a.V; ++v) {
         const size_t vg = (size_t)v * a.P + g;
-        const float4* rp = reinterpret_cast<const float4*>(a.rec + vg);
         const SplatAux ax = a.aux[vg];
         const int radius = ax.radius;
         float* o2 = a.dL_dmeans2D ? a.dL_dmeans2D + 3 * vg : nullptr;

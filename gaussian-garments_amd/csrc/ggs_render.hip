@@ -60,17 +60,6 @@ __device__ __forceinline__ float bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order, used for L2
-// locality only, never for correctness).  XCD k gets the tile ROWS r with r % 8 == k: the tiles
-// of a row share most of their splats (one 4 MB L2 sees each record), while interleaving rows
-// keeps the 8 XCDs evenly loaded when the garment covers only part of the image.
-// Grid: 8 * gx * ceil(gy / 8) workgroups per view; returns -1 for the padding.
-__device__ __forceinline__ int tile_of_block(int b, int gx, int gy) {
-    const int k = b & 7, i = b >> 3;
-    const int row = 8 * (i / gx) + k, col = i % gx;
-    return row < gy ? row * gx + col : -1;
-}
-
 __device__ __forceinline__ unsigned bcast_u(float v, int lane) {
     return (unsigned)__builtin_amdgcn_readlane(__float_as_int(v), lane);
 }
@@ -103,12 +92,11 @@ __device__ __forceinline__ Rec3 gather_round(const float4* __restrict__ rec, con
 
 }  // namespace
 
-// K4b: grid (8 * gx * ceil(gy/8), V), block 64.
+// K4b: grid V*T work items, block 64 (one wave per tile).
 __global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) {
     if (a.header->overflow) return;
-    const int t = tile_of_block(blockIdx.x, a.gx, a.gy);
-    if (t < 0) return;
-    const int v = blockIdx.y, lane = threadIdx.x;
+    const uint32_t item = a.order[blockIdx.x];       // (view, tile) work items, longest lists first
+    const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
     const int tx = t % a.gx, ty = t / a.gx;
     const int ox = tx * GGS_TILE, oy = ty * GGS_TILE;
     const int px0 = ox + (lane & 7), py0 = oy + (lane >> 3);
@@ -195,9 +183,8 @@ namespace {
 // K5 body.  DA: gradients of the depth / alpha outputs are present.
 template <bool DA>
 __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
-    const int t = tile_of_block(blockIdx.x, a.gx, a.gy);
-    if (t < 0) return;
-    const int v = blockIdx.y, lane = threadIdx.x;
+    const uint32_t item = a.order[blockIdx.x];       // (view, tile) work items, longest lists first
+    const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
     const int L = (int)a.tile_count[(size_t)v * a.T + t];
     if (L == 0) return;
     const int tx = t % a.gx, ty = t / a.gx;
@@ -324,7 +311,7 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
 
 }  // namespace
 
-// K5: grid (8 * gx * ceil(gy/8), V), block 64.  Two entry points so the common case (no loss on depth /
+// K5: grid V*T work items, block 64 (one wave per tile).  Two entry points so the common case (no loss on depth /
 // alpha: s2_registration.py:258-267, s3_appearance.py:131-140) carries no dead work.
 __global__ __launch_bounds__(64) void ggs_k_render_bwd(RenderBwdArgs a) { render_bwd_body<false>(a); }
 __global__ __launch_bounds__(64) void ggs_k_render_bwd_da(RenderBwdArgs a) { render_bwd_body<true>(a); }

@@ -144,7 +144,7 @@ int ggs_mesh_bind_backward(int P, int F, const float* verts, const int64_t* face
  * calling thread, ggs_forward / ggs_backward bracket each kernel with hipEvents on `stream`, synchronise
  * once at the end of the call, and keep the per-kernel milliseconds of that call.  ggs_profile_read copies
  * them out in the order {preprocess, scan_tiles, scatter, sort_tiles, render_fwd, render_bwd,
- * preprocess_bwd} and returns the count (7). */
+ * preprocess_bwd, order_tiles} and returns the count (8). */
 int ggs_profile_enable(int on);
 int ggs_profile_read(float* ms, int n);
 
