@@ -79,6 +79,7 @@ int check_params(const GgsParams* p) {
         return fail(GGS_ERR_ARG, "bad sizes P=%d W=%d H=%d n_views=%d", p->P, p->W, p->H, p->n_views);
     if (p->n_views > 65535) return fail(GGS_ERR_SIZE, "n_views=%d exceeds the grid.y limit 65535", p->n_views);
     if ((size_t)p->P * (size_t)p->n_views > (size_t)1 << 40) return fail(GGS_ERR_SIZE, "P*n_views too large");
+    if (p->P >= (1 << GGS_ID_BITS)) return fail(GGS_ERR_SIZE, "P=%d exceeds the 2^28 id space of the tile lists", p->P);
     return GGS_OK;
 }
 

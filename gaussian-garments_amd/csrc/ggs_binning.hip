@@ -102,31 +102,42 @@ __global__ __launch_bounds__(256) void ggs_k_order_tiles(OrderArgs a) {
 
 namespace {
 
-// Ascending-only bitonic network over `n2` = 2^m >= L slots; slots >= L are virtual +inf
-// keys, so a compare-exchange whose upper partner is >= L is a no-op.
+// sort order = (depth bits, Gaussian id); the quadrant mask riding in bits 28..31 is not part of it
+#define SORT_KEY(k) ((k) & ~((unsigned long long)0xf << GGS_ID_BITS))
+
 template <typename KeyPtr>
-__device__ __forceinline__ void bitonic_sort(KeyPtr key, int L, int n2, int tid, int nthreads) {
-    for (int k = 2; k <= n2; k <<= 1) {
-        // flip step: partner = mirror inside the block of size k
-        const int hk = k >> 1;
-        for (int t = tid; t < (n2 >> 1); t += nthreads) {
-            const int blk = t / hk, o = t - blk * hk;
-            const int i = blk * k + o, p = blk * k + k - 1 - o;
-            if (p < L) {
-                const unsigned long long a = key[i], b = key[p];
-                if (a > b) { key[i] = b; key[p] = a; }
-            }
+__device__ __forceinline__ void cmp_exchange(KeyPtr key, int i, int p, int L) {
+    if (p < L) {
+        const unsigned long long a = key[i], b = key[p];
+        if (SORT_KEY(a) > SORT_KEY(b)) { key[i] = b; key[p] = a; }
+    }
+}
+
+// Ascending-only bitonic network over `n2` = 2^m >= L slots; slots >= L are virtual +inf keys, so a
+// compare-exchange whose upper partner is >= L is a no-op.  Thread t handles pair-slot t (+256 m).
+// With 256 threads a wave64 owns the pairs of one aligned 128-element chunk, so every sub-step whose
+// partner distance is < 128 only touches data the SAME wave wrote: those need no workgroup barrier
+// (DS operations of one wave execute in order), only the compiler fence of wave_barrier().
+template <typename KeyPtr, bool WAVE_LOCAL_OK>
+__device__ __forceinline__ void bitonic_sort(KeyPtr key, int L, int n2, int tid) {
+    const int half = n2 >> 1;
+    for (int lk = 1; (1 << lk) <= n2; ++lk) {
+        const int k = 1 << lk, lhk = lk - 1;
+        // flip step: partner = mirror inside the block of size k (distance up to k - 1)
+        for (int t = tid; t < half; t += 256) {
+            const int blk = t >> lhk, o = t & ((1 << lhk) - 1);
+            cmp_exchange(key, (blk << lk) + o, (blk << lk) + k - 1 - o, L);
         }
-        __syncthreads();
-        for (int j = k >> 2; j > 0; j >>= 1) {
-            for (int t = tid; t < (n2 >> 1); t += nthreads) {
-                const int i = ((t / j) * (j << 1)) + (t % j), p = i + j;
-                if (p < L) {
-                    const unsigned long long a = key[i], b = key[p];
-                    if (a > b) { key[i] = b; key[p] = a; }
-                }
+        if (WAVE_LOCAL_OK && k <= 128) __builtin_amdgcn_wave_barrier(); else __syncthreads();
+        for (int lj = lk - 2; lj >= 0; --lj) {
+            const int j = 1 << lj;
+            for (int t = tid; t < half; t += 256) {
+                const int i = ((t >> lj) << (lj + 1)) + (t & (j - 1));
+                cmp_exchange(key, i, i + j, L);
             }
-            __syncthreads();
+            // the NEXT sub-step (distance j/2) reads what this one wrote: wave-local iff j <= 64
+            if (WAVE_LOCAL_OK && j <= 64 && !(lj == 0 && (k << 1) > 128)) __builtin_amdgcn_wave_barrier();
+            else __syncthreads();
         }
     }
 }
@@ -134,7 +145,7 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr key, int L, int n2, int tid,
 }  // namespace
 
 // K4a: grid V*T (work items in order[]), block 256.  Sorts the tile's key segment by (depth bits, id) and
-// writes the id list the render kernels walk.
+// writes the id-word list (quadrant mask << 28 | id) the render kernels walk.
 __global__ __launch_bounds__(256) void ggs_k_sort_tiles(SortArgs a) {
     if (a.header->overflow) return;
     const uint32_t item = a.order[blockIdx.x];
@@ -154,13 +165,14 @@ __global__ __launch_bounds__(256) void ggs_k_sort_tiles(SortArgs a) {
     if (L <= GGS_SORT_CAP) {
         for (int i = tid; i < L; i += 256) s_key[i] = keys[i];
         __syncthreads();
-        bitonic_sort(s_key, L, n2, tid, 256);
+        bitonic_sort<unsigned long long*, true>(s_key, L, n2, tid);
+        __syncthreads();
         for (int i = tid; i < L; i += 256) ids[i] = (uint32_t)s_key[i];
     } else {
         // Oversized list (pathological: > 4096 splats on one 16x16 tile): same network on the
         // global segment.  Slow but exact; plain loads/stores are ordered by __syncthreads
         // inside one workgroup (same CU, same L1).
-        bitonic_sort(keys, L, n2, tid, 256);
+        bitonic_sort<unsigned long long*, false>(keys, L, n2, tid);
         for (int i = tid; i < L; i += 256) ids[i] = (uint32_t)keys[i];
     }
 }

@@ -7,7 +7,8 @@
 //          SplatAux aux[V][P]            8 B: radius + SH clamp bits (binning / backward only).
 //   bin  : BinHeader | tile_count[V][T] | tile_cursor[V][T] | tile_offset[V][T] |
 //          view_base[V] | order[V*T] (work items v*T+t, heaviest tile lists first) |
-//          keys[cap] (u64: depth bits << 32 | Gaussian id) | ids[cap] (u32)
+//          keys[cap] (u64: depth bits << 32 | quadrant mask << 28 | Gaussian id) | ids[cap] (u32:
+//          quadrant mask << 28 | id, sorted by (depth bits, id))
 //          (BinHeader bytes 64.. hold the 8 list-length bucket counters / cursors of `order`)
 //   img  : final_T[V][H*W] f32 | n_contrib[V][H*W] u32
 //   bwd scratch : GradRec acc[V][P]      48 B per (view, Gaussian), atomically accumulated
@@ -22,6 +23,10 @@
 #define GGS_BLOCK 256            // threads per render block = one 16x16 tile = 4 wave64
 #define GGS_BATCH 256            // splats staged in LDS per round
 #define GGS_SORT_CAP 4096        // per-tile list length sorted in LDS (above: global fallback)
+// id word of the per-tile lists: bits 0..27 Gaussian id, bits 28..31 quadrant mask (bit q set: the
+// splat can reach / was blended in 8x8 quadrant q of the tile).  Limits P to 2^28.
+#define GGS_ID_BITS 28
+#define GGS_ID_MASK 0x0fffffffu
 #define GGS_NBUCKET 8             // list-length classes used to order the per-tile work items
 #define GGS_BUCKET_COUNT_OFF 64   // byte offsets inside the header region
 #define GGS_BUCKET_CURSOR_OFF 96
@@ -139,6 +144,16 @@ __device__ __forceinline__ void ggs_cull_rect(unsigned bbx, unsigned bby, int& x
     const int ty0 = ggs_bb_min(bby) >> 4, ty1 = (ggs_bb_max(bby) >> 4) + 1;
     x0 = x0 > tx0 ? x0 : tx0; x1 = x1 < tx1 ? x1 : tx1;
     y0 = y0 > ty0 ? y0 : ty0; y1 = y1 < ty1 ? y1 : ty1;
+}
+
+// Which 8x8 quadrants of tile (tx, ty) the alpha AABB reaches, positioned at bits 28..31 of the id word.
+__device__ __forceinline__ unsigned long long ggs_quad_mask(unsigned bbx, unsigned bby, int tx, int ty) {
+    const int xmin = ggs_bb_min(bbx), xmax = ggs_bb_max(bbx), ymin = ggs_bb_min(bby), ymax = ggs_bb_max(bby);
+    const int ox = tx * GGS_TILE, oy = ty * GGS_TILE;
+    const unsigned hx0 = xmin <= ox + 7 && xmax >= ox, hx1 = xmin <= ox + 15 && xmax >= ox + 8;
+    const unsigned hy0 = ymin <= oy + 7 && ymax >= oy, hy1 = ymin <= oy + 15 && ymax >= oy + 8;
+    const unsigned m = (hx0 & hy0) | ((hx1 & hy0) << 1) | ((hx0 & hy1) << 2) | ((hx1 & hy1) << 3);
+    return (unsigned long long)m << GGS_ID_BITS;
 }
 
 // Rotation matrix (row-major) of a (w,x,y,z) quaternion, no normalisation (A.0).

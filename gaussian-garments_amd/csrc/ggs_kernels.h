@@ -60,7 +60,7 @@ struct RenderArgs {
     const uint32_t* tile_count;
     const uint32_t* tile_offset;
     const unsigned long long* view_base;
-    const uint32_t* ids;
+    uint32_t* ids;            // forward narrows the quadrant masks to "actually blended" in place
     const SplatRec* rec;
     const float* bg;          // [V][3]
     float* out_color;         // [V][3][H][W]

@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
     const int v = blockIdx.y;
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     unsigned long long key = 0;
+    unsigned bbx = 1u, bby = 1u;
     bool has = false;
     if (g < a.P) {
         const int radius = a.aux[(size_t)v * a.P + g].radius;
@@ -196,7 +197,8 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
             const float4 r0 = reinterpret_cast<const float4*>(rec)[0];
             const float4 r2 = reinterpret_cast<const float4*>(rec)[2];
             ggs_tile_rect(r0.x, r0.y, (float)radius, a.gx, a.gy, x0, y0, x1, y1);
-            ggs_cull_rect(__float_as_uint(r2.z), __float_as_uint(r2.w), x0, y0, x1, y1);
+            bbx = __float_as_uint(r2.z); bby = __float_as_uint(r2.w);
+            ggs_cull_rect(bbx, bby, x0, y0, x1, y1);
             key = ((unsigned long long)__float_as_uint(r2.y) << 32) | (unsigned)g;
             has = x0 < x1 && y0 < y1;
         }
@@ -228,14 +230,14 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
             for (int y = y0; y < y1; ++y)
                 for (int x = x0; x < x1; ++x) {
                     const int i = (y - w.y0) * w.w + (x - w.x0);
-                    keys[(size_t)s_base[i] + atomicAdd(&s_cnt[i], 1u)] = key;
+                    keys[(size_t)s_base[i] + atomicAdd(&s_cnt[i], 1u)] = key | ggs_quad_mask(bbx, bby, x, y);
                 }
     } else if (has) {
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) {
                 const int t = y * a.gx + x;
                 const uint32_t slot = atomicAdd(&cur[t], 1u);
-                keys[(size_t)off[t] + slot] = key;
+                keys[(size_t)off[t] + slot] = key | ggs_quad_mask(bbx, bby, x, y);
             }
     }
 }

@@ -64,28 +64,16 @@ __device__ __forceinline__ unsigned bcast_u(float v, int lane) {
     return (unsigned)__builtin_amdgcn_readlane(__float_as_int(v), lane);
 }
 
-// Which 8x8 quadrants of the tile at pixel origin (ox, oy) the splat's alpha AABB reaches.
-// Everything here is wave-uniform integer work (SALU compares), so a quadrant the splat cannot
-// touch costs a scalar branch instead of a 64-lane alpha evaluation.
-struct QuadHit {
-    bool q[4];
-    __device__ __forceinline__ QuadHit(unsigned bbx, unsigned bby, int ox, int oy) {
-        const int xmin = ggs_bb_min(bbx), xmax = ggs_bb_max(bbx), ymin = ggs_bb_min(bby), ymax = ggs_bb_max(bby);
-        const bool hx0 = xmin <= ox + 7 && xmax >= ox, hx1 = xmin <= ox + 15 && xmax >= ox + 8;
-        const bool hy0 = ymin <= oy + 7 && ymax >= oy, hy1 = ymin <= oy + 15 && ymax >= oy + 8;
-        q[0] = hx0 && hy0; q[1] = hx1 && hy0; q[2] = hx0 && hy1; q[3] = hx1 && hy1;
-    }
-};
-
-struct Rec3 { float4 a, b, c; };
+struct Rec3 { float4 a, b, c; uint32_t w; };   // record of splat (first + lane) and its id word
 
 __device__ __forceinline__ Rec3 gather_round(const float4* __restrict__ rec, const uint32_t* __restrict__ ids,
                                              int first, int L, int lane) {
     int i = first + lane;
     i = i < L ? i : L - 1;
     i = i < 0 ? 0 : i;
-    const float4* r = rec + (size_t)ids[i] * 3;
     Rec3 o;
+    o.w = ids[i];
+    const float4* r = rec + (size_t)(o.w & GGS_ID_MASK) * 3;
     o.a = r[0]; o.b = r[1]; o.c = r[2];
     return o;
 }
@@ -102,7 +90,7 @@ __global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) {
     const int px0 = ox + (lane & 7), py0 = oy + (lane >> 3);
     const int L = (int)a.tile_count[(size_t)v * a.T + t];
     const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
-    const uint32_t* __restrict__ ids = a.ids + base;
+    uint32_t* ids = a.ids + base;
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
 
     float pxf[4], pyf[4], T[4], C0[4], C1[4], C2[4], D[4], A[4];
@@ -125,17 +113,21 @@ __global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) {
             const Rec3 cur = nxt;
             if (first + 64 < L) nxt = gather_round(rec, ids, first + 64, L, lane);
             const int n = min(64, L - first);
+            // id words of this round with the quadrant mask narrowed to the quadrants that actually blended
+            // the splat (0 for splats not reached): the backward skips everything else without testing
+            uint32_t neww = cur.w & GGS_ID_MASK;
             for (int j = 0; j < n; ++j) {
+                const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, j);
+                uint32_t blended = 0;
                 const float gx = bcast(cur.a.x, j), gy = bcast(cur.a.y, j);
                 const float cxx = bcast(cur.a.z, j), cxy = bcast(cur.a.w, j), cyy = bcast(cur.b.x, j);
                 const float op = bcast(cur.b.y, j);
                 const float cr = bcast(cur.b.z, j), cg = bcast(cur.b.w, j), cb = bcast(cur.c.x, j);
                 const float dep = bcast(cur.c.y, j);
-                const QuadHit hit(bcast_u(cur.c.z, j), bcast_u(cur.c.w, j), ox, oy);
                 const uint32_t pos = (uint32_t)(first + j + 1);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (!hit.q[q]) continue;                 // wave-uniform: one scalar branch
+                    if (!(word & (1u << (GGS_ID_BITS + q)))) continue;   // wave-uniform: one scalar branch
                     // predicated, branch-free per-pixel update: lane masks instead of nested exec juggling
                     const float dx = gx - pxf[q], dy = gy - pyf[q];
                     const float power = -0.5f * (cxx * dx * dx + cyy * dy * dy) - cxy * dx * dy;
@@ -154,9 +146,12 @@ __global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) {
                     A[q] += w;
                     T[q] = app ? test_T : T[q];
                     last[q] = app ? pos : last[q];
+                    if (__any(app)) blended |= 1u << (GGS_ID_BITS + q);
                 }
+                if (lane == j) neww |= blended;
                 if ((j & 15) == 15 && __all(done[0] && done[1] && done[2] && done[3])) break;
             }
+            if (lane < n) ids[first + lane] = neww;
         }
     }
 
@@ -240,37 +235,30 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
     // rounds of 64 list positions, walked from the back: round r covers [64 r, 64 r + 64)
     int r = (maxc - 1) >> 6;
     Rec3 nxt = gather_round(rec, ids, r * 64, L, lane);
-    uint32_t nxt_id = ids[min(r * 64 + lane, L - 1)];
     for (; r >= 0; --r) {
         const Rec3 cur = nxt;
-        const uint32_t cur_id = nxt_id;
-        if (r > 0) {
-            nxt = gather_round(rec, ids, (r - 1) * 64, L, lane);
-            nxt_id = ids[(r - 1) * 64 + lane];
-        }
+        if (r > 0) nxt = gather_round(rec, ids, (r - 1) * 64, L, lane);
         const int first = r * 64;
         const int n = min(64, maxc - first);
         for (int j = n - 1; j >= 0; --j) {
             const int pos = first + j;                  // list position; pixel q blended it iff pos < nc[q]
+            const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, j);
+            if (!(word >> GGS_ID_BITS)) continue;       // the forward blended this splat nowhere in the tile
             const float gx = bcast(cur.a.x, j), gy = bcast(cur.a.y, j);
             const float cxx = bcast(cur.a.z, j), cxy = bcast(cur.a.w, j), cyy = bcast(cur.b.x, j);
             const float op = bcast(cur.b.y, j);
             const float cr = bcast(cur.b.z, j), cg = bcast(cur.b.w, j), cb = bcast(cur.c.x, j);
             const float dep = bcast(cur.c.y, j);
-            const QuadHit hit(bcast_u(cur.c.z, j), bcast_u(cur.c.w, j), ox, oy);
             float v_mx = 0.f, v_my = 0.f, v_cx = 0.f, v_cy = 0.f, v_cz = 0.f, v_op = 0.f;
             float v_r = 0.f, v_g = 0.f, v_b = 0.f, v_dep = 0.f;
-            bool any_valid = false;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (!hit.q[q]) continue;                 // wave-uniform: scalar branch
+                if (!(word & (1u << (GGS_ID_BITS + q)))) continue;   // quadrant did not blend it (forward's mask)
                 const float dx = gx - pxf[q], dy = gy - pyf[q];
                 const float power = -0.5f * (cxx * dx * dx + cyy * dy * dy) - cxy * dx * dy;
                 const float Gr = __expf(power);
                 const float ar = ggs_min(GGS_ALPHA_MAX, op * Gr);
                 const bool valid = (pos < nc[q]) & (power <= 0.f) & (ar >= GGS_ALPHA_MIN);
-                if (!__any(valid)) continue;
-                any_valid = true;
                 // predication instead of branches: a lane that did not blend this splat carries
                 // alpha = G = 0, which zeroes every contribution and leaves (T, B) unchanged.
                 const float alpha = valid ? ar : 0.f;
@@ -293,12 +281,11 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
                 v_cz = fmaf(-0.5f * gdy * dy, dL_dG, v_cz);
                 v_op = fmaf(G, dL_da, v_op);
             }
-            if (!any_valid) continue;                   // (uniform) nobody in the tile blended this splat
             // totals land in: S1 lanes 15/31/47/63 = (mx, cx, my, cy); S2 = (cz, r, op, g); S3 lanes 31/63 = (b, depth)
             const float S1 = row_sum_lane15(swap16_add(swap32_add(v_mx, v_my), swap32_add(v_cx, v_cy)));
             const float S2 = row_sum_lane15(swap16_add(swap32_add(v_cz, v_op), swap32_add(v_r, v_g)));
             const float S3 = half_sum_lane31_63(swap32_add(v_b, v_dep));
-            const uint32_t gid = (uint32_t)__builtin_amdgcn_readlane((int)cur_id, j);
+            const uint32_t gid = word & GGS_ID_MASK;
             float* dst = reinterpret_cast<float*>(acc + gid);
             if ((lane & 15) == 15) {                         // 4 lanes issue 4 atomics per instruction
                 atomicAdd(dst + fld, S1);

@@ -144,7 +144,7 @@ def test_internals_bit_exact():
     sec = bin_sections(st)
     counts = sec["tile_count"].cpu().numpy().astype(np.int64).reshape(-1)
     offs = sec["tile_offset"].cpu().numpy().astype(np.int64).reshape(-1)
-    ids = sec["ids"].cpu().numpy().astype(np.uint32)
+    ids = sec["ids"].cpu().numpy().astype(np.uint32) & np.uint32(0x0fffffff)   # bits 28..31: quadrant mask
     assert st.num_rendered == counts.sum() <= co.num_rendered
     assert st.num_rendered > 0.5 * co.num_rendered
     xy, con = it["xy"], it["conic_opacity"]
