@@ -148,11 +148,18 @@ size_t ggs_backward_scratch_bytes(const GgsParams* p) {
     return ggs_align((size_t)p->n_views * (size_t)p->P * sizeof(GradRec));
 }
 
-int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const float* shs,
-                const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
-                const float* cov3D_precomp, const float* view, const float* proj, const float* campos,
-                const float* tanfov, void* geom, void* bin, size_t bin_capacity, void* img, float* out_color,
-                float* out_depth, float* out_alpha, int* radii, void* stream_) {
+}  // extern "C"
+
+namespace {
+enum { PHASE_COUNT = 1, PHASE_RENDER = 2 };
+
+// PHASE_COUNT : clear counters, preprocess (+ tile histogram), scan, work-item order  -> header.num_rendered
+// PHASE_RENDER: scatter keys, per-tile sort, composite
+int forward_impl(int phases, const GgsParams* p, const float* bg, const float* means3D, const float* shs,
+                 const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
+                 const float* cov3D_precomp, const float* view, const float* proj, const float* campos,
+                 const float* tanfov, void* geom, void* bin, size_t bin_capacity, void* img, float* out_color,
+                 float* out_depth, float* out_alpha, int* radii, void* stream_) {
     g_err[0] = 0;
     GGS_TRY(check_params(p));
     GGS_TRY(check_modes(p, shs, colors_precomp, scales, rotations, cov3D_precomp));
@@ -179,10 +186,10 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
     float* final_T = (float*)img;
     uint32_t* n_contrib = (uint32_t*)((char*)img + ggs_align((size_t)V * HW * 4));
 
+    const dim3 gridP((unsigned)((p->P + 255) / 256), (unsigned)V);
+    if (phases & PHASE_COUNT) {
     if (hipMemsetAsync(bin, 0, L.zero_bytes, s) != hipSuccess)
         return fail(GGS_ERR_HIP, "ggs_forward: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
-
-    const dim3 gridP((unsigned)((p->P + 255) / 256), (unsigned)V);
     if (p->P > 0) {
         PreArgs a;
         a.P = p->P; a.K = p->K; a.deg = p->sh_degree; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T;
@@ -213,6 +220,8 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
         prof_stop(K_ORDER, s);
         GGS_TRY(check("order_tiles", s, p->debug));
     }
+    }  // PHASE_COUNT
+    if (!(phases & PHASE_RENDER)) { prof_collect(s); return GGS_OK; }
     if (p->P > 0) {
         ScatterArgs a;
         a.P = p->P; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.rec = (const SplatRec*)geom; a.header = header;
@@ -223,7 +232,6 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
         prof_stop(K_SCATTER, s);
         GGS_TRY(check("scatter", s, p->debug));
     }
-    const dim3 gridT((unsigned)d.T, (unsigned)V);
     {
         SortArgs a;
         a.T = d.T; a.n_items = n_items; a.order = order; a.header = header; a.tile_count = tile_count;
@@ -247,6 +255,23 @@ int ggs_forward(const GgsParams* p, const float* bg, const float* means3D, const
     prof_collect(s);
     return GGS_OK;
 }
+}  // namespace
+
+extern "C" {
+
+#define GGS_FWD_PARAMS                                                                                              \
+    const GgsParams *p, const float *bg, const float *means3D, const float *shs, const float *colors_precomp,      \
+        const float *opacities, const float *scales, const float *rotations, const float *cov3D_precomp,           \
+        const float *view, const float *proj, const float *campos, const float *tanfov, void *geom, void *bin,     \
+        size_t bin_capacity, void *img, float *out_color, float *out_depth, float *out_alpha, int *radii,          \
+        void *stream_
+#define GGS_FWD_ARGS                                                                                                \
+    p, bg, means3D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, view, proj, campos, tanfov,   \
+        geom, bin, bin_capacity, img, out_color, out_depth, out_alpha, radii, stream_
+
+int ggs_forward(GGS_FWD_PARAMS) { return forward_impl(PHASE_COUNT | PHASE_RENDER, GGS_FWD_ARGS); }
+int ggs_forward_count(GGS_FWD_PARAMS) { return forward_impl(PHASE_COUNT, GGS_FWD_ARGS); }
+int ggs_forward_render(GGS_FWD_PARAMS) { return forward_impl(PHASE_RENDER, GGS_FWD_ARGS); }
 
 int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, const float* shs,
                  const float* colors_precomp, const float* scales, const float* rotations,

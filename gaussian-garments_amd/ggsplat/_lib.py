@@ -34,6 +34,8 @@ _SIGS = {
     "ggs_bin_layout": (C.c_int, [C.POINTER(GgsParams), C.c_size_t, C.POINTER(C.c_size_t)]),
     "ggs_backward_scratch_bytes": (C.c_size_t, [C.POINTER(GgsParams)]),
     "ggs_forward": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 6),
+    "ggs_forward_count": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 6),
+    "ggs_forward_render": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 6),
     "ggs_backward": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 13 + [C.c_size_t] + [_PTR] * 13 + [C.c_int, _PTR]),
     "ggs_mesh_bind_forward": (C.c_int, [C.c_int, C.c_int] + [_PTR] * 11),
     "ggs_mesh_bind_backward": (C.c_int, [C.c_int, C.c_int] + [_PTR] * 15),

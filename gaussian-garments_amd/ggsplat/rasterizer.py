@@ -7,8 +7,8 @@ the native backward.  Call site being served: gaussian_renderer/__init__.py:54,
 :103-111.  Differences, all MI355X-motivated:
   * the native side is a C ABI over caller-allocated workspaces (no resize callback);
   * one call can batch V views (grid dimension = view) over the same Gaussians;
-  * the only host sync is one 16-byte header read-back per call (num_rendered +
-    overflow flag), never per kernel.
+  * the only host sync is one 16-byte header read-back per call after the tile scan
+    (num_rendered + overflow flag), never per kernel; the compositing is queued behind it.
 """
 from __future__ import annotations
 
@@ -30,6 +30,28 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+_pinned: Dict = {}
+_tanfov_cache: Dict = {}
+
+
+def _pinned_header(dev) -> torch.Tensor:
+    t = _pinned.get(dev.index)
+    if t is None:
+        t = _pinned[dev.index] = torch.empty(2, dtype=torch.int64, pin_memory=True)
+    return t
+
+
+def tanfov_tensor(tanfovx: float, tanfovy: float, dev) -> torch.Tensor:
+    """[1,2] device tensor of the two tangents, cached per camera intrinsics (avoids an H2D copy per call)."""
+    k = (float(tanfovx), float(tanfovy), dev.index)
+    t = _tanfov_cache.get(k)
+    if t is None:
+        if len(_tanfov_cache) > 4096:
+            _tanfov_cache.clear()
+        t = _tanfov_cache[k] = torch.tensor([[tanfovx, tanfovy]], dtype=torch.float32, device=dev)
+    return t
 
 
 def _stream_ptr(dev) -> C.c_void_p:
@@ -76,25 +98,30 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
     key = (dev.index, P, W, H, V)
     cap = _cap_hint.get(key, max(8 * P * V, 1 << 16))
     stream = _stream_ptr(dev)
-    host = torch.empty(2, dtype=torch.int64, pin_memory=True)
+    host = _pinned_header(dev)
+    geom = img = None
     while True:
         gsz, isz, bsz = C.c_size_t(), C.c_size_t(), C.c_size_t()
         check(L.ggs_workspace_sizes(C.byref(prm), cap, C.byref(gsz), C.byref(isz), C.byref(bsz)), "ggs_workspace_sizes")
-        geom = torch.empty(gsz.value, device=dev, dtype=torch.uint8)
-        img = torch.empty(isz.value, device=dev, dtype=torch.uint8)
+        if geom is None:
+            geom = torch.empty(gsz.value, device=dev, dtype=torch.uint8)
+            img = torch.empty(isz.value, device=dev, dtype=torch.uint8)
         binb = torch.empty(bsz.value, device=dev, dtype=torch.uint8)
-        check(L.ggs_forward(C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities),
-                            ptr(scales), ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos),
-                            ptr(tanfov), ptr(geom), ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha),
-                            ptr(radii), stream), "ggs_forward")
+        args = (C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales),
+                ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov), ptr(geom),
+                ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha), ptr(radii), stream)
+        # phase 1: preprocess + tile histogram + scan.  The ONLY host sync of the call waits for these ~10 us
+        # of GPU work (the upstream extension syncs at the same point to size its binning buffer).
+        check(L.ggs_forward_count(*args), "ggs_forward_count")
         host.copy_(binb[:16].view(torch.int64), non_blocking=True)
         torch.cuda.current_stream(dev).synchronize()
         n, overflow = int(host[0]), int(host[1])
         if not overflow:
-            _cap_hint[key] = max(cap, 1 << 16) if n * 2 <= cap else int(n * 2)
             break
-        cap = int(n * 1.5) + 1024          # n is exact even when the segment was too small
-        _cap_hint[key] = cap
+        cap = int(n * 1.25) + 1024             # n is exact: one retry is always enough
+    _cap_hint[key] = max(cap if n * 2 <= cap else int(n * 2), 1 << 16)
+    # phase 2: scatter + sort + composite, queued without waiting
+    check(L.ggs_forward_render(*args), "ggs_forward_render")
     st = None
     if keep_state:
         st = ForwardState()
@@ -162,7 +189,7 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
         dev = means3D.device
-        tanfov = torch.tensor([[settings.tanfovx, settings.tanfovy]], dtype=torch.float32, device=dev)
+        tanfov = tanfov_tensor(settings.tanfovx, settings.tanfovy, dev)
         color, radii, depth, alpha, st = forward_views(
             means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp,
             view=settings.viewmatrix, proj=settings.projmatrix, campos=settings.campos, tanfov=tanfov,

@@ -102,6 +102,26 @@ int ggs_forward(const GgsParams* prm, const float* bg, const float* means3D, con
                 float* out_depth, float* out_alpha, int* radii, void* stream);
 
 /*
+ * Two-phase forward with the SAME argument list, for callers that want to size the binning buffer
+ * exactly (what the upstream extension does through its resize callback after the tile scan):
+ *   ggs_forward_count  : preprocess + tile histogram + scan -> header.num_rendered is final once the
+ *                        stream reaches this point (read the header back; ~10 us of GPU work);
+ *   ggs_forward_render : key scatter + per-tile sort + compositing, on the same geom/bin/img buffers.
+ * If header.overflow is set after the count phase, call it again with a binning buffer of at least
+ * num_rendered entries before rendering.  ggs_forward == count followed by render.
+ */
+int ggs_forward_count(const GgsParams* prm, const float* bg, const float* means3D, const float* shs,
+                      const float* colors_precomp, const float* opacities, const float* scales,
+                      const float* rotations, const float* cov3D_precomp, const float* view, const float* proj,
+                      const float* campos, const float* tanfov, void* geom, void* bin, size_t bin_capacity,
+                      void* img, float* out_color, float* out_depth, float* out_alpha, int* radii, void* stream);
+int ggs_forward_render(const GgsParams* prm, const float* bg, const float* means3D, const float* shs,
+                       const float* colors_precomp, const float* opacities, const float* scales,
+                       const float* rotations, const float* cov3D_precomp, const float* view, const float* proj,
+                       const float* campos, const float* tanfov, void* geom, void* bin, size_t bin_capacity,
+                       void* img, float* out_color, float* out_depth, float* out_alpha, int* radii, void* stream);
+
+/*
  * Backward.  dL_dcolor [V][3][H][W]; dL_ddepth / dL_dalpha [V][H][W] or NULL (zero).
  * geom / bin / img / bin_capacity: exactly what the matching ggs_forward call was given.
  * scratch: ggs_backward_scratch_bytes() bytes.

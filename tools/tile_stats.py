@@ -26,3 +26,29 @@ for vi in (0, 40, 100, 159):
     pct = lambda a: [int(np.percentile(a, q)) for q in (50, 90, 99, 100)]
     print(f"view {vi}: N={cnt.sum()} active tiles={act.sum()} L pct50/90/99/max={pct(cnt[act])} processed(max n_contrib per tile) pct={pct(tmax[act])} "
           f"sum L={cnt.sum()} sum processed={tmax.sum()} mean n_contrib/covered px={float(ncon[ncon>0].float().mean()):.1f} covered px={int((ncon>0).sum())} radii mean={float(radii.float().mean()):.1f}")
+
+# ---- quadrant-mask statistics for the last view ----
+sec = R.bin_sections(st)
+cnt = sec["tile_count"][0].cpu().numpy().astype(np.int64)
+off = sec["tile_offset"][0].cpu().numpy().astype(np.int64)
+words = sec["ids"].cpu().numpy().astype(np.uint32)[:int(cnt.sum())]
+recs = st.geom[:100000 * 48].view(torch.int32).reshape(100000, 12).cpu().numpy()
+tile_of = np.repeat(np.arange(len(cnt)), cnt)
+# list position within tile
+posn = np.arange(len(words)) - np.repeat(off, cnt)
+processed = posn < np.repeat(tmax, cnt)
+gid = words & 0x0fffffff
+blend = (words >> 28).astype(np.int64)
+bbx, bby = recs[gid, 10].astype(np.int64), recs[gid, 11].astype(np.int64)
+sx = lambda w: ((w & 0xffff) ^ 0x8000) - 0x8000
+xmin, xmax, ymin, ymax = sx(bbx), bbx >> 16, sx(bby), bby >> 16
+ox, oy = (tile_of % 120) * 16, (tile_of // 120) * 16
+hx0 = (xmin <= ox + 7) & (xmax >= ox); hx1 = (xmin <= ox + 15) & (xmax >= ox + 8)
+hy0 = (ymin <= oy + 7) & (ymax >= oy); hy1 = (ymin <= oy + 15) & (ymax >= oy + 8)
+aabb_bits = (hx0 & hy0).astype(int) + (hx1 & hy0) + (hx0 & hy1) + (hx1 & hy1)
+pop = np.array([bin(i).count("1") for i in range(16)])
+bl_bits = pop[blend]
+p = processed
+print(f"entries={len(words)} processed={p.sum()} AABB quadrants/processed entry={aabb_bits[p].mean():.2f} "
+      f"blended quadrants/processed entry={bl_bits[p].mean():.2f} entries with no blend={(bl_bits[p]==0).mean():.2%} "
+      f"blended quadrants / AABB quadrants={bl_bits[p].sum()/aabb_bits[p].sum():.2%}")
