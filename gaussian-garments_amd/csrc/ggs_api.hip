@@ -99,6 +99,14 @@ int check_modes(const GgsParams* p, const void* shs, const void* colors, const v
     return GGS_OK;
 }
 
+// View-loop splits of the per-Gaussian backward: ~8k waves keep 256 CUs busy.
+int bwd_splits(const GgsParams* p) {
+    if (p->P <= 0) return 1;
+    const int waves = (p->P + 63) / 64;
+    int s = (8192 + waves - 1) / waves;
+    return s < 1 ? 1 : (s > p->n_views ? p->n_views : s);
+}
+
 struct Dims { int gx, gy, T; };
 Dims dims(const GgsParams* p) {
     Dims d;
@@ -145,7 +153,9 @@ int ggs_bin_layout(const GgsParams* p, size_t bin_capacity, size_t offsets[8]) {
 
 size_t ggs_backward_scratch_bytes(const GgsParams* p) {
     if (!p || p->P < 0 || p->n_views <= 0) return 0;
-    return ggs_align((size_t)p->n_views * (size_t)p->P * sizeof(GradRec));
+    const int splits = bwd_splits(p);
+    const size_t part = splits > 1 ? (size_t)splits * (14 + 3 * (size_t)p->K) * (size_t)p->P * 4 : 0;
+    return ggs_align((size_t)p->n_views * (size_t)p->P * sizeof(GradRec)) + ggs_align(part);
 }
 
 }  // extern "C"
@@ -234,10 +244,12 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
     }
     {
         SortArgs a;
-        a.T = d.T; a.n_items = n_items; a.order = order; a.header = header; a.tile_count = tile_count;
-        a.tile_offset = tile_offset; a.view_base = view_base; a.keys = keys; a.ids = ids;
+        a.T = d.T; a.n_items = n_items; a.order = order; a.bucket_count = bucket_count; a.header = header;
+        a.tile_count = tile_count; a.tile_offset = tile_offset; a.view_base = view_base; a.keys = keys; a.ids = ids;
         prof_start(K_SORT, s);
-        hipLaunchKernelGGL(ggs_k_sort_tiles, dim3((unsigned)n_items), dim3(256), 0, s, a);
+        // persistent grids sized for the chip (256 CUs), not for the item count: most items are empty tiles
+        hipLaunchKernelGGL(ggs_k_sort_tiles, dim3((unsigned)(n_items < 1280 ? n_items : 1280)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(ggs_k_sort_tiles_wave, dim3((unsigned)((n_items + 3) / 4 < 2048 ? (n_items + 3) / 4 : 2048)), dim3(256), 0, s, a);
         prof_stop(K_SORT, s);
         GGS_TRY(check("sort_tiles", s, p->debug));
     }
@@ -332,7 +344,20 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
         a.dL_dmeans2D = dL_dmeans2D; a.dL_dmeans3D = dL_dmeans3D; a.dL_dopac = dL_dopacities; a.dL_dsh = dL_dshs;
         a.dL_dcolors = dL_dcolors; a.dL_dscales = dL_dscales; a.dL_drots = dL_drotations; a.dL_dcov3D = dL_dcov3D;
         prof_start(K_PRE_BWD, s);
-        hipLaunchKernelGGL(ggs_k_preprocess_bwd, dim3((unsigned)((p->P + 255) / 256)), dim3(256), 0, s, a);
+        // enough lanes to fill 256 CUs: split the view loop when P alone gives < ~8k waves
+        const int splits = bwd_splits(p);
+        a.part = splits > 1 ? (float*)((char*)scratch + ggs_align((size_t)V * p->P * sizeof(GradRec))) : nullptr;
+        const dim3 grid((unsigned)((p->P + 255) / 256), (unsigned)splits);
+        switch (colors_precomp ? 0 : p->sh_degree) {
+            case 0: hipLaunchKernelGGL(ggs_k_preprocess_bwd_sh0, grid, dim3(256), 0, s, a); break;
+            case 1: hipLaunchKernelGGL(ggs_k_preprocess_bwd_sh1, grid, dim3(256), 0, s, a); break;
+            case 2: hipLaunchKernelGGL(ggs_k_preprocess_bwd_sh2, grid, dim3(256), 0, s, a); break;
+            default: hipLaunchKernelGGL(ggs_k_preprocess_bwd_sh3, grid, dim3(256), 0, s, a); break;
+        }
+        if (splits > 1) {
+            const size_t n = (size_t)(14 + 3 * p->K) * p->P;
+            hipLaunchKernelGGL(ggs_k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, splits);
+        }
         prof_stop(K_PRE_BWD, s);
         GGS_TRY(check("preprocess_bwd", s, p->debug));
     }

@@ -144,24 +144,74 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr key, int L, int n2, int tid)
 
 }  // namespace
 
-// K4a: grid V*T (work items in order[]), block 256.  Sorts the tile's key segment by (depth bits, id) and
+// K4a-small: persistent grid, block 256 = 4 independent wave64s, ONE TILE PER WAVE for lists of up to
+// GGS_SORT_WAVE_CAP keys: each wave sorts in its private 4 KB LDS slice with the whole network
+// wave-local -- no workgroup barrier at all, and every lane carries n2/128 independent
+// compare-exchanges per sub-step (ILP hides the LDS latency the 256-thread version exposed).
+#define GGS_SORT_WAVE_CAP 512
+__global__ __launch_bounds__(256) void ggs_k_sort_tiles_wave(SortArgs a) {
+    if (a.header->overflow) return;
+    __shared__ unsigned long long s_all[4][GGS_SORT_WAVE_CAP];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const NonEmptyItems it = ggs_nonempty_items(a.bucket_count, (uint32_t)a.n_items);
+    unsigned long long* key = s_all[wave];
+    // persistent waves over the non-empty work items only (the empty ~90 % of an image never cost a
+    // workgroup launch); round-robin over a longest-first list keeps the waves evenly loaded
+    for (uint32_t r = blockIdx.x * 4 + wave; r < it.n; r += gridDim.x * 4) {
+    const uint32_t item = a.order[(size_t)r * it.stride];
+    const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T);
+    const int L = (int)a.tile_count[(size_t)v * a.T + t];
+    if (L > GGS_SORT_WAVE_CAP) continue;                  // longer lists: ggs_k_sort_tiles
+    const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
+    const unsigned long long* keys = a.keys + base;
+    uint32_t* ids = a.ids + base;
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < L; i += 64) key[i] = keys[i];
+    __builtin_amdgcn_wave_barrier();
+    int n2 = 2;
+    while (n2 < L) n2 <<= 1;
+    const int half = n2 >> 1;
+    for (int lk = 1; (1 << lk) <= n2; ++lk) {
+        const int k = 1 << lk, lhk = lk - 1;
+#pragma unroll 4
+        for (int p = lane; p < half; p += 64) {
+            const int blk = p >> lhk, o = p & ((1 << lhk) - 1);
+            cmp_exchange(key, (blk << lk) + o, (blk << lk) + k - 1 - o, L);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int lj = lk - 2; lj >= 0; --lj) {
+            const int j = 1 << lj;
+#pragma unroll 4
+            for (int p = lane; p < half; p += 64) {
+                const int i = ((p >> lj) << (lj + 1)) + (p & (j - 1));
+                cmp_exchange(key, i, i + j, L);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    for (int i = lane; i < L; i += 64) ids[i] = (uint32_t)key[i];
+    }
+}
+
+// K4a-large: persistent grid over the work items with more than GGS_SORT_WAVE_CAP keys (first in order[]), block 256.
+// Sorts the tile's key segment by (depth bits, id) and
 // writes the id-word list (quadrant mask << 28 | id) the render kernels walk.
 __global__ __launch_bounds__(256) void ggs_k_sort_tiles(SortArgs a) {
     if (a.header->overflow) return;
-    const uint32_t item = a.order[blockIdx.x];
-    const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), tid = threadIdx.x;
+    const int tid = threadIdx.x;
+    const NonEmptyItems it = ggs_nonempty_items(a.bucket_count, (uint32_t)a.n_items);
+    __shared__ unsigned long long s_key[GGS_SORT_CAP];
+    for (uint32_t r = blockIdx.x; r < it.n_long; r += gridDim.x) {
+    const uint32_t item = a.order[(size_t)r * it.stride];
+    const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T);
     const int L = (int)a.tile_count[(size_t)v * a.T + t];
-    if (L == 0) return;
+    __syncthreads();                                      // s_key reuse across iterations
+    if (L <= GGS_SORT_WAVE_CAP) continue;                 // short lists: ggs_k_sort_tiles_wave
     const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
     unsigned long long* keys = a.keys + base;
     uint32_t* ids = a.ids + base;
-    if (L == 1) {
-        if (tid == 0) ids[0] = (uint32_t)keys[0];
-        return;
-    }
     int n2 = 2;
     while (n2 < L) n2 <<= 1;
-    __shared__ unsigned long long s_key[GGS_SORT_CAP];
     if (L <= GGS_SORT_CAP) {
         for (int i = tid; i < L; i += 256) s_key[i] = keys[i];
         __syncthreads();
@@ -174,5 +224,6 @@ __global__ __launch_bounds__(256) void ggs_k_sort_tiles(SortArgs a) {
         // inside one workgroup (same CU, same L1).
         bitonic_sort<unsigned long long*, false>(keys, L, n2, tid);
         for (int i = tid; i < L; i += 256) ids[i] = (uint32_t)keys[i];
+    }
     }
 }

@@ -104,6 +104,20 @@ __device__ __forceinline__ int ggs_len_bucket(uint32_t L) {
     return lg <= 5 ? 6 : (lg >= 11 ? 0 : 11 - lg);
 }
 
+// Position in order[] of the r-th non-empty work item (longest first); mirrors ggs_k_order_tiles.
+struct NonEmptyItems {
+    uint32_t n, stride;        // n non-empty items, at order[r * stride]
+    uint32_t n_long;           // the first n_long of them have >= 512 splats (classes 0..2)
+};
+__device__ __forceinline__ NonEmptyItems ggs_nonempty_items(const uint32_t* bucket_count, uint32_t n_items) {
+    const uint32_t E = bucket_count[GGS_NBUCKET - 1];
+    NonEmptyItems it;
+    it.n = n_items - E;
+    it.stride = (it.n ? (E / it.n) & ~1u : 0) + 1;
+    it.n_long = bucket_count[0] + bucket_count[1] + bucket_count[2];
+    return it;
+}
+
 // Tile rectangle of a splat (A.1 step 6); must be bit-identical wherever it is recomputed.
 __device__ __forceinline__ void ggs_tile_rect(float px, float py, float r, int gx, int gy, int& x0, int& y0,
                                               int& x1, int& y1) {

@@ -45,6 +45,7 @@ struct ScatterArgs {
 struct SortArgs {
     int T, n_items;
     const uint32_t* order;
+    const uint32_t* bucket_count;
     const GgsBinHeader* header;
     const uint32_t* tile_count;
     const uint32_t* tile_offset;
@@ -96,6 +97,7 @@ struct PreBwdArgs {
     const SplatAux* aux;
     const GradRec* acc;
     float *dL_dmeans2D, *dL_dmeans3D, *dL_dopac, *dL_dsh, *dL_dcolors, *dL_dscales, *dL_drots, *dL_dcov3D;
+    float* part;              // [splits][14 + 3K][P] partial sums (only when the view loop is split)
 };
 
 __global__ void ggs_k_preprocess(PreArgs a);
@@ -103,10 +105,15 @@ __global__ void ggs_k_scan_tiles(ScanArgs a);
 __global__ void ggs_k_scatter(ScatterArgs a);
 __global__ void ggs_k_order_tiles(OrderArgs a);
 __global__ void ggs_k_sort_tiles(SortArgs a);
+__global__ void ggs_k_sort_tiles_wave(SortArgs a);
 __global__ void ggs_k_render_fwd(RenderArgs a);
 __global__ void ggs_k_render_bwd(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_da(RenderBwdArgs a);
-__global__ void ggs_k_preprocess_bwd(PreBwdArgs a);
+__global__ void ggs_k_preprocess_bwd_sh0(PreBwdArgs a);
+__global__ void ggs_k_preprocess_bwd_sh1(PreBwdArgs a);
+__global__ void ggs_k_preprocess_bwd_sh2(PreBwdArgs a);
+__global__ void ggs_k_preprocess_bwd_sh3(PreBwdArgs a);
+__global__ void ggs_k_reduce_partials(PreBwdArgs a, int splits);
 
 // host-side error plumbing (ggs_api.hip)
 int ggs_fail_(int code, const char* fmt, ...);

@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
 namespace {
 
 template <int DEG>
-__device__ __forceinline__ void sh_backward(const float* __restrict__ sh, float* __restrict__ dsh, bool accumulate,
+__device__ __forceinline__ void sh_backward(const float* __restrict__ sh, float* dshr,
                                             const float* d, float len, const float* g_rgb, float* dmean) {
     constexpr int NK = (DEG + 1) * (DEG + 1);
     float bas[NK];
@@ -259,7 +259,7 @@ __device__ __forceinline__ void sh_backward(const float* __restrict__ sh, float*
         for (int ch = 0; ch < 3; ++ch) {
             const float gch = g_rgb[ch];
             const float val = bas[k] * gch;
-            if (accumulate) dsh[k * 3 + ch] += val; else dsh[k * 3 + ch] = val;
+            dshr[k * 3 + ch] += val;        // summed over this lane's views in registers
             acc += sh[k * 3 + ch] * gch;
         }
         sg[k] = acc;
@@ -300,9 +300,26 @@ __device__ __forceinline__ void sh_backward(const float* __restrict__ sh, float*
 
 }  // namespace
 
-// K6: grid ceil(P/256).  One lane per Gaussian loops over the V views, so the sums over
-// views need no atomics and are deterministic.
-__global__ __launch_bounds__(256) void ggs_k_preprocess_bwd(PreBwdArgs a) {
+// K6: grid (ceil(P/256), S).  One lane per Gaussian loops over the views v = y, y + S, ... and keeps
+// every sum over views in registers (incl. the (DEG+1)^2 x 3 SH gradient).  S = 1: plain stores,
+// deterministic view sum.  S > 1 (enough waves to fill the chip when P is small against 256 CUs):
+// each split adds its partial sums atomically into outputs the host zeroed.
+namespace {
+// Address of output component c of Gaussian g (nullptr: not produced in this input mode).
+__device__ __forceinline__ float* ggs_grad_slot(const PreBwdArgs& a, int c, int g) {
+    if (c < 3) return a.dL_dmeans3D + 3 * (size_t)g + c;
+    if (c == 3) return a.dL_dopac + g;
+    if (c < 11) {
+        if (a.cov3d) return (c < 10 && a.dL_dcov3D) ? a.dL_dcov3D + 6 * (size_t)g + (c - 4) : nullptr;
+        if (c < 7) return a.dL_dscales ? a.dL_dscales + 3 * (size_t)g + (c - 4) : nullptr;
+        return a.dL_drots ? a.dL_drots + 4 * (size_t)g + (c - 7) : nullptr;
+    }
+    if (c < 14) return (a.colors && a.dL_dcolors) ? a.dL_dcolors + 3 * (size_t)g + (c - 11) : nullptr;
+    return (!a.colors && a.dL_dsh) ? a.dL_dsh + (size_t)g * a.K * 3 + (c - 14) : nullptr;
+}
+
+template <int DEG>
+__device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a) {
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= a.P) return;
     const float m[3] = {a.means3D[3 * (size_t)g], a.means3D[3 * (size_t)g + 1], a.means3D[3 * (size_t)g + 2]};
@@ -318,10 +335,14 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess_bwd(PreBwdArgs a) {
     }
     float dmean[3] = {0.f, 0.f, 0.f}, dcov[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float dop = 0.f, dcol[3] = {0.f, 0.f, 0.f};
-    bool sh_written = a.accumulate != 0;
+    constexpr int NK = (DEG + 1) * (DEG + 1);
+    float dshr[NK * 3];
+#pragma unroll
+    for (int k = 0; k < NK * 3; ++k) dshr[k] = 0.f;
     float* dsh = a.dL_dsh ? a.dL_dsh + (size_t)g * a.K * 3 : nullptr;
+    const bool split = gridDim.y > 1;
 
-    for (int v = 0; v < a.V; ++v) {
+    for (int v = blockIdx.y; v < a.V; v += gridDim.y) {
         const size_t vg = (size_t)v * a.P + g;
         const SplatAux ax = a.aux[vg];
         const int radius = ax.radius;
@@ -400,35 +421,34 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess_bwd(PreBwdArgs a) {
             const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             d[0] = d[0] / len; d[1] = d[1] / len; d[2] = d[2] / len;
             const float* sh = a.shs + (size_t)g * a.K * 3;
-            switch (a.deg) {
-                case 0: sh_backward<0>(sh, dsh, sh_written, d, len, gsh, dmean); break;
-                case 1: sh_backward<1>(sh, dsh, sh_written, d, len, gsh, dmean); break;
-                case 2: sh_backward<2>(sh, dsh, sh_written, d, len, gsh, dmean); break;
-                default: sh_backward<3>(sh, dsh, sh_written, d, len, gsh, dmean); break;
-            }
-            sh_written = true;
+            sh_backward<DEG>(sh, dshr, d, len, gsh, dmean);
         }
     }
 
+    // Output component c of Gaussian g: 0-2 means3D | 3 opacity | 4-6 scales or 4-9 cov3D | 7-10 rotations |
+    // 11-13 colours | 14 + 3k + ch SH.  One view split: straight to the gradient tensors.  Several splits:
+    // to this split's slab of the partial buffer part[split][c][g] (coalesced), summed by
+    // ggs_k_reduce_partials -- no atomics, deterministic.
     const bool acc = a.accumulate != 0;
+    const int NC = 14 + 3 * a.K;
+    auto put = [&](int c, float v) {
+        if (split) { a.part[((size_t)blockIdx.y * NC + c) * a.P + g] = v; return; }
+        float* p = ggs_grad_slot(a, c, g);
+        if (acc) *p += v; else *p = v;
+    };
     if (dsh && !a.colors) {
-        const int nk = (a.deg + 1) * (a.deg + 1);
-        // coefficients above the active degree (and everything if no view saw the splat) get zero
-        for (int k = sh_written ? nk : 0; k < a.K; ++k)
-            if (!acc) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
+#pragma unroll
+        for (int k = 0; k < NK * 3; ++k) put(14 + k, dshr[k]);
+        if (!acc && !split)                     // coefficients above the active degree get zero
+            for (int k = NK * 3; k < a.K * 3; ++k) dsh[k] = 0.f;
     }
-    auto put = [acc](float* p, float v) { if (acc) *p += v; else *p = v; };
-    put(a.dL_dmeans3D + 3 * (size_t)g, dmean[0]); put(a.dL_dmeans3D + 3 * (size_t)g + 1, dmean[1]);
-    put(a.dL_dmeans3D + 3 * (size_t)g + 2, dmean[2]);
-    put(a.dL_dopac + g, dop);
-    if (a.colors && a.dL_dcolors) {
-        put(a.dL_dcolors + 3 * (size_t)g, dcol[0]); put(a.dL_dcolors + 3 * (size_t)g + 1, dcol[1]);
-        put(a.dL_dcolors + 3 * (size_t)g + 2, dcol[2]);
-    }
+    put(0, dmean[0]); put(1, dmean[1]); put(2, dmean[2]);
+    put(3, dop);
+    if (a.colors && a.dL_dcolors) { put(11, dcol[0]); put(12, dcol[1]); put(13, dcol[2]); }
     if (a.cov3d) {
         if (a.dL_dcov3D)
 #pragma unroll
-            for (int k = 0; k < 6; ++k) put(a.dL_dcov3D + 6 * (size_t)g + k, dcov[k]);
+            for (int k = 0; k < 6; ++k) put(4 + k, dcov[k]);
     } else if (a.dL_dscales && a.dL_drots) {
         // Sigma = M^T M, M[k][j] = s_k R[j][k]  ->  dM = 2 M Gs, ds_k = sum_j dM[k][j] R[j][k], dR[j][k] = s_k dM[k][j]
         float R[9], Mm[9], sv[3];
@@ -458,9 +478,29 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess_bwd(PreBwdArgs a) {
         const float dq1 = 2.f * (y * dR[1] + z * dR[2] + y * dR[3] - 2.f * x * dR[4] - r * dR[5] + z * dR[6] + r * dR[7] - 2.f * x * dR[8]);
         const float dq2 = 2.f * (-2.f * y * dR[0] + x * dR[1] + r * dR[2] + x * dR[3] + z * dR[5] - r * dR[6] + z * dR[7] - 2.f * y * dR[8]);
         const float dq3 = 2.f * (-2.f * z * dR[0] - r * dR[1] + x * dR[2] + r * dR[3] - 2.f * z * dR[4] + y * dR[5] + x * dR[6] + y * dR[7]);
-        put(a.dL_dscales + 3 * (size_t)g, ds[0]); put(a.dL_dscales + 3 * (size_t)g + 1, ds[1]);
-        put(a.dL_dscales + 3 * (size_t)g + 2, ds[2]);
-        put(a.dL_drots + 4 * (size_t)g, dq0); put(a.dL_drots + 4 * (size_t)g + 1, dq1);
-        put(a.dL_drots + 4 * (size_t)g + 2, dq2); put(a.dL_drots + 4 * (size_t)g + 3, dq3);
+        put(4, ds[0]); put(5, ds[1]); put(6, ds[2]);
+        put(7, dq0); put(8, dq1); put(9, dq2); put(10, dq3);
     }
+}
+}  // namespace
+
+// one kernel per SH degree: the register footprint (and occupancy) follows the degree actually used
+__global__ __launch_bounds__(256) void ggs_k_preprocess_bwd_sh0(PreBwdArgs a) { preprocess_bwd_body<0>(a); }
+__global__ __launch_bounds__(256) void ggs_k_preprocess_bwd_sh1(PreBwdArgs a) { preprocess_bwd_body<1>(a); }
+__global__ __launch_bounds__(256) void ggs_k_preprocess_bwd_sh2(PreBwdArgs a) { preprocess_bwd_body<2>(a); }
+__global__ __launch_bounds__(256) void ggs_k_preprocess_bwd_sh3(PreBwdArgs a) { preprocess_bwd_body<3>(a); }
+
+// K6b: grid ceil(P * NC / 256).  Sums the per-split partials part[s][c][g] into the gradient tensors.
+__global__ __launch_bounds__(256) void ggs_k_reduce_partials(PreBwdArgs a, int splits) {
+    const int NC = 14 + 3 * a.K;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)NC * a.P) return;
+    const int c = (int)(idx / a.P), g = (int)(idx % a.P);
+    float* dst = ggs_grad_slot(a, c, g);
+    if (!dst) return;
+    const int nk3 = a.colors ? 0 : 3 * (a.deg + 1) * (a.deg + 1);
+    float sum = 0.f;
+    if (c < 14 + nk3)                            // SH coefficients above the active degree were never written
+        for (int s = 0; s < splits; ++s) sum += a.part[((size_t)s * NC + c) * a.P + g];
+    if (a.accumulate) *dst += sum; else *dst = sum;
 }

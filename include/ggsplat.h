@@ -85,7 +85,8 @@ int ggs_workspace_sizes(const GgsParams* prm, size_t bin_capacity, size_t* geom_
  *  keys [cap] u64, ids [cap] u32, total}.  Not part of the reference's interface. */
 int ggs_bin_layout(const GgsParams* prm, size_t bin_capacity, size_t offsets[8]);
 
-/* Bytes of the gradient-accumulator scratch ggs_backward needs (V*P*48). */
+/* Bytes of the scratch ggs_backward needs: V*P*48 for the per-(view, Gaussian) gradient accumulators, plus
+ * the per-split partial sums of the per-Gaussian stage when its view loop is split (small P). */
 size_t ggs_backward_scratch_bytes(const GgsParams* prm);
 
 /*
