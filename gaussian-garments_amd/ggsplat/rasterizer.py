@@ -167,6 +167,11 @@ def backward_views(st: ForwardState, dL_dcolor, dL_ddepth=None, dL_dalpha=None, 
     return g
 
 
+def _alias(t: torch.Tensor, shape) -> torch.Tensor:
+    """A tensor over the same storage as contiguous `t` with a new shape that autograd does not see as a view."""
+    return t.new_empty(0).set_(t.untyped_storage(), t.storage_offset(), tuple(shape))
+
+
 def bin_sections(st: ForwardState) -> Dict[str, torch.Tensor]:
     """Typed views into the binning buffer of a forward (tests / debugging)."""
     off = (C.c_size_t * 8)()
@@ -198,9 +203,13 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.set_materialize_grads(False)      # unused depth / alpha outputs -> None, not zeros
         ctx.st = st
         ctx.m2d_shape = means2D.shape
-        # outputs are never saved: callers mutate them in place (utils/loss_utils.py:44-46)
-        ctx.mark_non_differentiable(radii)
-        return color[0], radii[0], depth, alpha
+        # Outputs are never saved: callers mutate them in place (ssim does `img1 *= mask`,
+        # utils/loss_utils.py:44-46).  For the same reason they must not be VIEWS created inside this
+        # Function (autograd refuses in-place ops on those): alias the storage with fresh tensors.
+        color1 = _alias(color, (3, settings.image_height, settings.image_width))
+        radii1 = _alias(radii, (radii.shape[1],))
+        ctx.mark_non_differentiable(radii1)
+        return color1, radii1, depth, alpha
 
     @staticmethod
     def backward(ctx, g_color, g_radii, g_depth, g_alpha):

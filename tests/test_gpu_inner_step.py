@@ -1,0 +1,149 @@
+"""Rows a13 / a14 of the scope table: the s2 registration step and the s3 appearance step on the GPU
+(HIP rasterizer + fused mesh binding + PyTorch loss) against the same step assembled from the
+oracles on the CPU (host_oracle.mesh_bind + torch_oracle.rasterize + host_oracle loss, autograd).
+Compared per step: loss terms, image, radii, EVERY parameter gradient (incl. mesh.v), the
+densification statistics; the Adam step itself is checked on the gradients it consumed."""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import rel_l1
+from ggsplat import synthetic as S
+from oracle import host_oracle as HO
+from oracle import torch_oracle as TO
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-4
+W, H = 64, 64
+
+
+def _scene(sh_degree, seed=0):
+    v, f = S.skirt_mesh(24, 40, r_top=0.30, r_bottom=0.5, height=0.8, jitter=2e-3, seed=seed)   # 1920 faces
+    params = S.skirt_gaussian_params(f.shape[0], sh_degree=sh_degree, seed=seed)
+    g = torch.Generator().manual_seed(seed + 5)
+    params["_xyz"] = torch.randn(f.shape[0], 3, generator=g) * 0.3
+    cams = S.rig_cameras(n_rings=2, n_az=3, radius=2.2, width=W, height=H, f=60.0, seed=seed)
+    gt = torch.rand(3, H, W, generator=g)
+    mask = (torch.rand(1, H, W, generator=g) > 0.2).float()
+    return v, f, params, cams, gt, mask
+
+
+def _oracle_render(cam, xyz, scaling, rot, opacity, shs, sh_degree, bg):
+    P = xyz.shape[0]
+    m2d = torch.zeros(P, 3, requires_grad=True)
+    color, radii, depth, alpha = TO.rasterize(
+        xyz, m2d, opacity, shs=shs, scales=scaling, rotations=rot, viewmatrix=cam.world_view_transform.cpu(),
+        projmatrix=cam.full_proj_transform.cpu(), campos=cam.camera_center.cpu(), bg=bg, W=W, H=H,
+        tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), sh_degree=sh_degree)
+    return color, radii, m2d
+
+
+def _photometric(image, gt, mask, lam):
+    return HO.l1_loss(image, gt, mask) * (1.0 - lam), 1.0 - HO.ssim(image, gt, mask) * lam
+
+
+def test_registration_step_matches_oracle_pipeline():
+    from ggsplat.inner_step import DEFAULT_OPT, registration_step
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "threshold_xyz": 0.3, "threshold_scale": 0.5})
+    v, f, params, cams, gt, mask = _scene(sh_degree=0)
+    model = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
+    model.training_setup(opt, is_ff=True)
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+    for it, cam_i in enumerate((0, 4)):
+        cam = cams[cam_i]
+        for n in ("world_view_transform", "full_proj_transform", "camera_center"):
+            setattr(cam, n, getattr(cam, n).cuda())
+        # ---- oracle pipeline from the CURRENT GPU parameters (no drift between the two sides) ----
+        leaf = {n: getattr(model, n).detach().cpu().clone().requires_grad_(True) for n in names}
+        mv = model.mesh.v.detach().cpu().clone().requires_grad_(True)
+        xyz, scaling, rot = HO.mesh_bind(mv, f, params["binding"], leaf["_xyz"], leaf["_scaling"], leaf["_rotation"])
+        shs = torch.cat((leaf["_features_dc"], leaf["_features_rest"]), 1)
+        image, radii, m2d = _oracle_render(cam, xyz, scaling, rot, torch.sigmoid(leaf["_opacity"]), shs, 0, bg)
+        vis = radii > 0
+        l_img, l_ssim = _photometric(image, gt, mask, opt.lambda_dssim)
+        l_xyz = F.relu(leaf["_xyz"][vis].norm(dim=1) - opt.threshold_xyz).mean() * opt.lambda_xyz
+        l_sc = F.relu(torch.exp(leaf["_scaling"][vis]) - opt.threshold_scale).norm(dim=1).mean() * opt.lambda_scale
+        (l_img + l_ssim + l_xyz + l_sc).backward()
+        # ---- GPU step (no optimizer step yet: compare the gradients it will consume) ----
+        accum_before = model.xyz_gradient_accum.clone()
+        out = registration_step(model, cam, gt.cuda(), mask.cuda(), bg.cuda(), opt=opt, optimizer_step=False)
+        assert abs(float(out["img"]) - float(l_img)) < 1e-5 and abs(float(out["ssim"]) - float(l_ssim)) < 1e-5
+        assert abs(float(out["xyz"]) - float(l_xyz)) < 1e-6 and abs(float(out["scale"]) - float(l_sc)) < 1e-6
+        assert np.array_equal(out["render_pkg"]["radii"].cpu().numpy(), radii.numpy())
+        for n in names:
+            gpu_g = getattr(model, n).grad
+            if leaf[n].grad is None or float(leaf[n].grad.abs().sum()) == 0:
+                assert gpu_g is None or float(gpu_g.abs().sum()) == 0
+                continue
+            assert rel_l1(gpu_g, leaf[n].grad) <= TOL, n
+        assert rel_l1(model.mesh.v.grad, mv.grad) <= TOL
+        assert rel_l1(out["render_pkg"]["viewspace_points"].grad, m2d.grad) <= TOL
+        stat = (model.xyz_gradient_accum - accum_before).cpu()
+        ref = torch.zeros_like(stat)
+        ref[vis] = m2d.grad[vis, :2].norm(dim=-1, keepdim=True)
+        assert rel_l1(stat, ref) <= TOL
+        assert torch.equal(model.denom.cpu().squeeze(1) >= it + 1, vis | (model.denom.cpu().squeeze(1) >= it + 1))
+        # ---- Adam(eps=1e-15) step on those gradients: first step moves every touched entry by exactly lr ----
+        before = {n: getattr(model, n).detach().clone() for n in names}
+        grads = {n: getattr(model, n).grad.clone() for n in names if getattr(model, n).grad is not None}
+        model.optimizer.step()
+        model.optimizer.zero_grad()
+        if it == 0:
+            lr = {"_xyz": opt.position_lr_init, "_opacity": opt.opacity_lr, "_scaling": opt.scaling_lr, "_rotation": opt.rotation_lr}
+            for n, l in lr.items():
+                moved = (getattr(model, n).detach() - before[n])
+                big = grads[n].abs() > 1e-10
+                assert torch.allclose(moved[big], -l * torch.sign(grads[n][big]), rtol=1e-3, atol=l * 1e-3), n
+
+
+def test_appearance_step_matches_oracle_pipeline():
+    """s3 form: barycentric origin, local_xyz = _xyz + net offset, shs = features + net offset, vis_mask gather."""
+    from ggsplat.inner_step import DEFAULT_OPT, appearance_step
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "threshold_xyz": 0.3, "threshold_scale": 0.5})
+    v, f, params, cams, gt, mask = _scene(sh_degree=1, seed=3)
+    P = f.shape[0]
+    g = torch.Generator().manual_seed(9)
+    bc = torch.rand(P, 3, generator=g)
+    bc = bc / bc.sum(1, keepdim=True)
+    model = MeshGaussianModel.from_tensors(v, f, params, sh_degree=1, device="cuda", gs_bc=bc)
+    net_w = torch.randn(3, 3, generator=g) * 0.05           # a tiny stand-in "network": offsets linear in _xyz
+    sh_off = torch.randn(P, 4, 3, generator=g) * 0.05
+    vis_mask = torch.rand(P, generator=g) > 0.5
+    cam = cams[2]
+    for n in ("world_view_transform", "full_proj_transform", "camera_center"):
+        setattr(cam, n, getattr(cam, n).cuda())
+    bg = torch.tensor([0.2, 0.3, 0.1])
+    wg = net_w.clone().cuda().requires_grad_(True)
+
+    def net(gm, c):
+        return gm._xyz @ wg, sh_off.cuda(), vis_mask.cuda()
+
+    out = appearance_step(model, net, cam, gt.cuda(), mask.cuda(), bg.cuda(), opt=opt)
+    # ---- oracle ----
+    names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+    leaf = {n: params[n].clone().requires_grad_(True) for n in names}
+    wc = net_w.clone().requires_grad_(True)
+    mv = v.clone().requires_grad_(True)
+    local = leaf["_xyz"] + leaf["_xyz"] @ wc
+    xyz, scaling, rot = HO.mesh_bind(mv, f, params["binding"], local, leaf["_scaling"], leaf["_rotation"], bary=bc)
+    shs = torch.cat((leaf["_features_dc"], leaf["_features_rest"]), 1) + sh_off
+    opacity = torch.sigmoid(leaf["_opacity"])
+    image, radii, m2d = _oracle_render(cam, xyz[vis_mask], scaling[vis_mask], rot[vis_mask], opacity[vis_mask], shs[vis_mask], 1, bg)
+    l_img, l_ssim = _photometric(image, gt, mask, opt.lambda_dssim)
+    l_xyz = F.relu(local.norm(dim=1) - opt.threshold_xyz).mean() * opt.lambda_xyz
+    l_sc = F.relu(torch.exp(leaf["_scaling"]) - opt.threshold_scale).norm(dim=1).mean() * opt.lambda_scale
+    l_op = F.relu(opt.threshold_opacity - opacity).mean() * opt.lambda_opacity
+    (l_img + l_ssim + l_xyz + l_sc + l_op).backward()
+    assert abs(float(out["loss"]) - float(l_img + l_ssim + l_xyz + l_sc + l_op)) < 2e-5
+    assert np.array_equal(out["render_pkg"]["radii"].cpu().numpy(), radii.numpy())
+    for n in names:
+        assert rel_l1(getattr(model, n).grad, leaf[n].grad) <= TOL, n
+    assert rel_l1(model.mesh.v.grad, mv.grad) <= TOL
+    assert rel_l1(wg.grad, wc.grad) <= TOL
