@@ -174,8 +174,17 @@ def main():
         dom_bytes = B[dom] * chunk
         achieved = dom_bytes / (group_ms[dom] * 1e-3) / 1e9
         B_view = sum(B.values())
+        # HBM bytes per launch from the PMC counters (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes,
+        # tools/hbm_traffic.sh; committed under profiles/ because bench.py cannot run a profiler on itself)
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
+            if args.sh_degree == 0 and (W, H, Fn) == (1920, 1080, 100000):
+                traffic = int(tj["kernels"]["ggs_k_" + dom]["traffic_per_view"] * chunk)
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": "ggs_k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "launch_views": chunk, "launch_ms": round(group_ms[dom], 4),
                     "alg_bytes_per_launch": int(dom_bytes),
                     "kernel_ms_per_launch": {k: round(v, 4) for k, v in kern_ms.items()},
