@@ -160,14 +160,69 @@ __device__ __forceinline__ void ggs_cull_rect(unsigned bbx, unsigned bby, int& x
     y0 = y0 > ty0 ? y0 : ty0; y1 = y1 < ty1 ? y1 : ty1;
 }
 
-// Which 8x8 quadrants of tile (tx, ty) the alpha AABB reaches, positioned at bits 28..31 of the id word.
-__device__ __forceinline__ unsigned long long ggs_quad_mask(unsigned bbx, unsigned bby, int tx, int ty) {
+// ---- exact (conservative) footprint test -----------------------------------------------------------
+// alpha >= 1/255 inside a pixel box [x0,x1] x [y0,y1] needs  min over the box of  q(d) = A dx^2 + 2 B dx dy + C dy^2
+// <= 2 tau  (d = pixel - mean, (A,B,C) = conic, tau = ln(255 opacity) with safety margins).  q is convex: the
+// minimum over the box is 0 if the mean is inside, else it sits on one of the four edges, where it is a
+// clamped 1-D parabola.  The box is continuous, so this is a superset of what any pixel centre can pass.
+struct Footprint { float mx, my, A, B, C, lim, BoC, BoA; };   // lim = 2 tau (<= 0: never blended); B/C, B/A
+
+__device__ __forceinline__ Footprint ggs_footprint(float px, float py, float cx, float cy, float cz, float opacity) {
+    Footprint f;
+    f.mx = px; f.my = py; f.A = cx; f.B = cy; f.C = cz;
+    const float tau = (opacity > 0.f ? logf(255.f * opacity) : -1.f) * 1.01f + 0.02f;
+    f.lim = 2.f * tau;
+    f.BoC = cy / cz; f.BoA = cy / cx;
+    return f;
+}
+
+__device__ __forceinline__ float ggs_edge_min_x(const Footprint& f, float xe, float y0, float y1) {   // x fixed
+    const float dx = xe - f.mx;
+    const float dy = ggs_min(y1 - f.my, ggs_max(y0 - f.my, -f.BoC * dx));   // clamped 1-D minimiser
+    return f.A * dx * dx + 2.f * f.B * dx * dy + f.C * dy * dy;
+}
+__device__ __forceinline__ float ggs_edge_min_y(const Footprint& f, float ye, float x0, float x1) {   // y fixed
+    const float dy = ye - f.my;
+    const float dx = ggs_min(x1 - f.mx, ggs_max(x0 - f.mx, -f.BoA * dy));
+    return f.A * dx * dx + 2.f * f.B * dx * dy + f.C * dy * dy;
+}
+// Only the edges FACING the mean can hold the minimum: from any point of the box the segment to the mean
+// decreases q and leaves the box through one of them.
+__device__ __forceinline__ bool ggs_box_reachable(const Footprint& f, float x0, float y0, float x1, float y1) {
+    const bool left = f.mx < x0, right = f.mx > x1, above = f.my < y0, below = f.my > y1;
+    if (!(left || right || above || below)) return f.lim > 0.f;          // mean inside the box
+    float q = 3.0e38f;
+    if (left) q = ggs_edge_min_x(f, x0, y0, y1);
+    if (right) q = ggs_edge_min_x(f, x1, y0, y1);
+    if (above) q = ggs_min(q, ggs_edge_min_y(f, y0, x0, x1));
+    if (below) q = ggs_min(q, ggs_edge_min_y(f, y1, x0, x1));
+    return q <= f.lim;
+}
+
+// Which 8x8 quadrants of tile (tx, ty) the splat can be blended in, positioned at bits 28..31 of the id word;
+// 0 = the tile can be dropped from the splat's list (output-invariant).  The AABB pre-test is integer work.
+__device__ __forceinline__ unsigned long long ggs_quad_mask(const Footprint& f, unsigned bbx, unsigned bby, int tx,
+                                                            int ty) {
     const int xmin = ggs_bb_min(bbx), xmax = ggs_bb_max(bbx), ymin = ggs_bb_min(bby), ymax = ggs_bb_max(bby);
     const int ox = tx * GGS_TILE, oy = ty * GGS_TILE;
-    const unsigned hx0 = xmin <= ox + 7 && xmax >= ox, hx1 = xmin <= ox + 15 && xmax >= ox + 8;
-    const unsigned hy0 = ymin <= oy + 7 && ymax >= oy, hy1 = ymin <= oy + 15 && ymax >= oy + 8;
-    const unsigned m = (hx0 & hy0) | ((hx1 & hy0) << 1) | ((hx0 & hy1) << 2) | ((hx1 & hy1) << 3);
+    const bool hx0 = xmin <= ox + 7 && xmax >= ox, hx1 = xmin <= ox + 15 && xmax >= ox + 8;
+    const bool hy0 = ymin <= oy + 7 && ymax >= oy, hy1 = ymin <= oy + 15 && ymax >= oy + 8;
+    const float fx = (float)ox, fy = (float)oy;
+    unsigned m = 0;
+    if (hx0 && hy0 && ggs_box_reachable(f, fx, fy, fx + 7.f, fy + 7.f)) m |= 1u;
+    if (hx1 && hy0 && ggs_box_reachable(f, fx + 8.f, fy, fx + 15.f, fy + 7.f)) m |= 2u;
+    if (hx0 && hy1 && ggs_box_reachable(f, fx, fy + 8.f, fx + 7.f, fy + 15.f)) m |= 4u;
+    if (hx1 && hy1 && ggs_box_reachable(f, fx + 8.f, fy + 8.f, fx + 15.f, fy + 15.f)) m |= 8u;
+    // The LIST MEMBERSHIP of the tile is decided by ggs_tile_reachable alone (used identically by the histogram
+    // and the scatter).  If rounding makes all four quadrant tests fail on a tile that passed, keep the AABB mask.
+    if (!m) m = (hx0 && hy0 ? 1u : 0u) | (hx1 && hy0 ? 2u : 0u) | (hx0 && hy1 ? 4u : 0u) | (hx1 && hy1 ? 8u : 0u);
     return (unsigned long long)m << GGS_ID_BITS;
+}
+
+// Can the splat be blended anywhere in tile (tx, ty)?  (the tile is already inside the culled rectangle)
+__device__ __forceinline__ bool ggs_tile_reachable(const Footprint& f, int tx, int ty) {
+    const float fx = (float)(tx * GGS_TILE), fy = (float)(ty * GGS_TILE);
+    return ggs_box_reachable(f, fx, fy, fx + 15.f, fy + 15.f);
 }
 
 // Rotation matrix (row-major) of a (w,x,y,z) quaternion, no normalisation (A.0).

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
         ggs_cull_rect(out.bbx, out.bby, x0, y0, x1, y1);
         has = x0 < x1 && y0 < y1;
     }
+    const Footprint fp = ggs_footprint(out.px, out.py, out.cx, out.cy, out.cz, out.opacity);
     uint32_t* cnt = a.tile_count + (size_t)v * a.T;
     const TileWindow w = block_tile_window(s_box, has, x0, y0, x1, y1);
     if (w.dense) {
@@ -164,7 +165,8 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
         __syncthreads();
         if (has)
             for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) atomicAdd(&s_cnt[(y - w.y0) * w.w + (x - w.x0)], 1u);
+                for (int x = x0; x < x1; ++x)
+                    if (ggs_tile_reachable(fp, x, y)) atomicAdd(&s_cnt[(y - w.y0) * w.w + (x - w.x0)], 1u);
         __syncthreads();
         for (int i = threadIdx.x; i < area; i += 256) {
             const uint32_t c = s_cnt[i];
@@ -172,7 +174,8 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
         }
     } else if (has) {
         for (int y = y0; y < y1; ++y)
-            for (int x = x0; x < x1; ++x) atomicAdd(&cnt[y * gx + x], 1u);
+            for (int x = x0; x < x1; ++x)
+                if (ggs_tile_reachable(fp, x, y)) atomicAdd(&cnt[y * gx + x], 1u);
     }
 }
 
@@ -189,6 +192,7 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
     int x0 = 0, y0 = 0, x1 = 0, y1 = 0;
     unsigned long long key = 0;
     unsigned bbx = 1u, bby = 1u;
+    Footprint fp = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 0.f, 0.f};
     bool has = false;
     if (g < a.P) {
         const int radius = a.aux[(size_t)v * a.P + g].radius;
@@ -197,7 +201,9 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
             const float4 r0 = reinterpret_cast<const float4*>(rec)[0];
             const float4 r2 = reinterpret_cast<const float4*>(rec)[2];
             ggs_tile_rect(r0.x, r0.y, (float)radius, a.gx, a.gy, x0, y0, x1, y1);
+            const float4 r1 = reinterpret_cast<const float4*>(rec)[1];
             bbx = __float_as_uint(r2.z); bby = __float_as_uint(r2.w);
+            fp = ggs_footprint(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
             ggs_cull_rect(bbx, bby, x0, y0, x1, y1);
             key = ((unsigned long long)__float_as_uint(r2.y) << 32) | (unsigned)g;
             has = x0 < x1 && y0 < y1;
@@ -215,7 +221,8 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
         __syncthreads();
         if (has)
             for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) atomicAdd(&s_cnt[(y - w.y0) * w.w + (x - w.x0)], 1u);
+                for (int x = x0; x < x1; ++x)
+                    if (ggs_tile_reachable(fp, x, y)) atomicAdd(&s_cnt[(y - w.y0) * w.w + (x - w.x0)], 1u);
         __syncthreads();
         for (int i = threadIdx.x; i < area; i += 256) {
             const uint32_t c = s_cnt[i];
@@ -229,15 +236,19 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
         if (has)
             for (int y = y0; y < y1; ++y)
                 for (int x = x0; x < x1; ++x) {
+                    if (!ggs_tile_reachable(fp, x, y)) continue;
+                    const unsigned long long qm = ggs_quad_mask(fp, bbx, bby, x, y);
                     const int i = (y - w.y0) * w.w + (x - w.x0);
-                    keys[(size_t)s_base[i] + atomicAdd(&s_cnt[i], 1u)] = key | ggs_quad_mask(bbx, bby, x, y);
+                    keys[(size_t)s_base[i] + atomicAdd(&s_cnt[i], 1u)] = key | qm;
                 }
     } else if (has) {
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x) {
+                if (!ggs_tile_reachable(fp, x, y)) continue;
+                const unsigned long long qm = ggs_quad_mask(fp, bbx, bby, x, y);
                 const int t = y * a.gx + x;
                 const uint32_t slot = atomicAdd(&cur[t], 1u);
-                keys[(size_t)off[t] + slot] = key | ggs_quad_mask(bbx, bby, x, y);
+                keys[(size_t)off[t] + slot] = key | qm;
             }
     }
 }
