@@ -55,17 +55,35 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_all_reduce_matches_single_process():
+def _run_two_ranks():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda x: x[0])
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
+        for p in procs:
+            p.join(timeout=60)
+        if any(p.exitcode != 0 for p in procs):
+            return None
+        return res
+    except Exception:
+        return None
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+
+
+def test_two_rank_gradient_all_reduce_matches_single_process():
+    res = None
+    for _ in range(3):                      # a rendezvous can lose a port race on a busy box: retry with a new port
+        res = _run_two_ranks()
+        if res is not None:
+            break
+    assert res is not None, "gloo world-size-2 run failed 3 times"
     shapes = [(6, 3), (6, 1), (6, 1, 3), (4, 3)]
     expect = [torch.zeros(s) for s in shapes]
     for v in range(10):
