@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-views", type=int, default=2, help="views of the workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--loop-views", type=int, default=16, help="views timed through the per-view drop-in render() loop")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for functional tests)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="functional test only: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
 
 
@@ -67,11 +70,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if args.single_device:
+        local_rank = 0
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
+    if world > 1:
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     from ggsplat import batch, synthetic as S
     from ggsplat import _lib
