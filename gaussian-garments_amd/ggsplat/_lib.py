@@ -39,6 +39,9 @@ _SIGS = {
     "ggs_backward": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 13 + [C.c_size_t] + [_PTR] * 13 + [C.c_int, _PTR]),
     "ggs_mesh_bind_forward": (C.c_int, [C.c_int, C.c_int] + [_PTR] * 11),
     "ggs_mesh_bind_backward": (C.c_int, [C.c_int, C.c_int] + [_PTR] * 15),
+    "ggs_photometric_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "ggs_photometric_forward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 6),
+    "ggs_photometric_backward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 7),
     "ggs_profile_enable": (C.c_int, [C.c_int]),
     "ggs_profile_read": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
     "ggs_last_error": (C.c_char_p, []),

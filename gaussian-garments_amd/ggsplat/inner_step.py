@@ -11,7 +11,7 @@ from typing import Callable, Dict, Optional
 import torch
 import torch.nn.functional as F
 
-from .loss import l1_loss, ssim
+from .loss import fused_photometric_loss, l1_loss, ssim
 from .render import render
 
 DEFAULT_OPT = SimpleNamespace(                      # arguments/__init__.py:74-116 (the values the steps read)
@@ -21,17 +21,26 @@ DEFAULT_OPT = SimpleNamespace(                      # arguments/__init__.py:74-1
 DEFAULT_PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
 
 
+def _photometric(image, gt_image, m, lam, fused: bool):
+    """The two image terms of both loops: L1 * (1 - lambda) and 1 - SSIM * lambda.  fused=True: one pair of HIP
+    kernels (ggs_photometric_*); fused=False: the reference's PyTorch composition (loss.py), which also masks
+    `image` and `gt_image` in place like the reference does."""
+    if fused:
+        return fused_photometric_loss(image, gt_image, m, lam)
+    return l1_loss(image, gt_image, m) * (1.0 - lam), 1.0 - ssim(image, gt_image, m) * lam
+
+
 def registration_step(gaussians, viewpoint_cam, gt_image, mask, bg, opt=DEFAULT_OPT, pipe=DEFAULT_PIPE,
                       first_frame_template: bool = True, track_densification: bool = True,
-                      optimizer_step: bool = True) -> Dict[str, torch.Tensor]:
+                      optimizer_step: bool = True, fused_loss: bool = False) -> Dict[str, torch.Tensor]:
     """One iteration of the s2 loop: update_face_coor -> render -> L1 (1 - lambda) + (1 - ssim lambda)
     [+ xyz / scale hinges on the first template frame] -> backward -> densification stats -> Adam step."""
     gaussians.update_face_coor()
     pkg = render(viewpoint_cam, gaussians, pipe, bg)
     image, vsp, vis, radii = pkg["render"], pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]
     m = mask if opt.only_foreground_loss else None
-    loss_dict = {"img": l1_loss(image, gt_image, m) * (1.0 - opt.lambda_dssim),
-                 "ssim": 1.0 - ssim(image, gt_image, m) * opt.lambda_dssim}
+    l_img, l_ssim = _photometric(image, gt_image, m, opt.lambda_dssim, fused_loss)
+    loss_dict = {"img": l_img, "ssim": l_ssim}
     if first_frame_template:
         loss_dict["xyz"] = F.relu(gaussians._xyz[vis].norm(dim=1) - opt.threshold_xyz).mean() * opt.lambda_xyz
         loss_dict["scale"] = F.relu(gaussians.scaling_activation(gaussians._scaling[vis]) - opt.threshold_scale
@@ -51,7 +60,7 @@ def registration_step(gaussians, viewpoint_cam, gt_image, mask, bg, opt=DEFAULT_
 
 
 def appearance_step(gaussians, net: Callable, viewpoint_cam, gt_image, mask, bg, optimizer=None,
-                    opt=DEFAULT_OPT, pipe=DEFAULT_PIPE) -> Dict[str, torch.Tensor]:
+                    opt=DEFAULT_OPT, pipe=DEFAULT_PIPE, fused_loss: bool = False) -> Dict[str, torch.Tensor]:
     """One iteration of the s3 loop.  `net(gaussians, cam) -> (xyz_offset [P,3], sh_offset [P,K,3], vis_mask [P])`
     stands in for AvatarNet.forward (scene/avatar_net.py:58-87): it sets local_xyz = _xyz + offset and
     shs = get_features + offset, then render(..., vis_mask=vis_mask) and the five-term loss."""
@@ -62,8 +71,8 @@ def appearance_step(gaussians, net: Callable, viewpoint_cam, gt_image, mask, bg,
     pkg = render(viewpoint_cam, gaussians, pipe, bg, vis_mask=vis_mask)
     image = pkg["render"]
     m = mask if opt.only_foreground_loss else None
-    loss_dict = {"img": l1_loss(image, gt_image, m) * (1.0 - opt.lambda_dssim),
-                 "ssim": 1.0 - ssim(image, gt_image, m) * opt.lambda_dssim,
+    l_img, l_ssim = _photometric(image, gt_image, m, opt.lambda_dssim, fused_loss)
+    loss_dict = {"img": l_img, "ssim": l_ssim,
                  "xyz": F.relu(gaussians.local_xyz.norm(dim=1) - opt.threshold_xyz).mean() * opt.lambda_xyz,
                  "scale": F.relu(gaussians.scaling_activation(gaussians._scaling) - opt.threshold_scale
                                  ).norm(dim=1).mean() * opt.lambda_scale,

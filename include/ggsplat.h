@@ -161,6 +161,23 @@ int ggs_mesh_bind_backward(int P, int F, const float* verts, const int64_t* face
                            const float* dL_drotation, float* dL_dverts, float* dL_dlocal_xyz,
                            float* dL_dlog_scaling, float* dL_draw_rot, void* stream);
 
+/*
+ * Fused photometric loss of the inner steps ("next" #1): masked L1 + 11x11 Gaussian-window
+ * SSIM, value and gradient w.r.t. the rendered image, replacing utils/loss_utils.py:17-68 (l1_loss, ssim) as
+ * composed at s2_registration.py:259-260 and s3_appearance.py:132-133.
+ *   img, gt [V][3][H][W]; mask [V][1][H][W] or NULL (x = img*mask, y = gt*mask like the reference's in-place masking)
+ * forward : sums [V][2] (device) <- { sum |x - y| , sum ssim_map(x, y) }  (means = sums / (3 H W)); the per-pixel
+ *           derivative maps of the SSIM map stay in `scratch` (ggs_photometric_scratch_bytes() bytes).
+ * backward: weights [V][2] (device) = { dLoss/d mean|x-y| , dLoss/d mean ssim_map } per view
+ *           (the reference's loss (1-lambda) L1 + 1 - lambda SSIM gives {1-lambda, -lambda} times the upstream grad);
+ *           dL_dimg [V][3][H][W] <- d Loss / d img.  Same img / gt / mask / scratch as the forward call.
+ */
+size_t ggs_photometric_scratch_bytes(int n_views, int H, int W);
+int ggs_photometric_forward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
+                            float* sums, void* scratch, void* stream);
+int ggs_photometric_backward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
+                             const void* scratch, const float* weights, float* dL_dimg, void* stream);
+
 /* Profiling aid (bench.py roofline leg; not part of the reference's interface).  While enabled on the
  * calling thread, ggs_forward / ggs_backward bracket each kernel with hipEvents on `stream`, synchronise
  * once at the end of the call, and keep the per-kernel milliseconds of that call.  ggs_profile_read copies

@@ -1,0 +1,91 @@
+"""Fused photometric loss (ggs_photometric_forward / _backward) against the PyTorch restatement of
+utils/loss_utils.py (oracle/host_oracle.py, itself pinned to golden vectors of the reference):
+values and gradients, with / without mask, ragged sizes, batched views, unequal upstream weights."""
+import os
+import time
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_l1
+from oracle import host_oracle as HO
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _ref(img, gt, mask, lam, wa=1.0, wb=1.0):
+    x = img.clone().requires_grad_(True)
+    l_img = HO.l1_loss(x, gt, mask) * (1.0 - lam)
+    l_ssim = 1.0 - HO.ssim(x, gt, mask) * lam
+    (wa * l_img + wb * l_ssim).backward()
+    return float(l_img), float(l_ssim), x.grad
+
+
+@pytest.mark.parametrize("H,W,use_mask", [(48, 64, True), (48, 64, False), (37, 53, True), (70, 33, False), (11, 9, True)])
+def test_fused_loss_matches_reference_restatement(H, W, use_mask):
+    from ggsplat.loss import fused_photometric_loss
+    g = torch.Generator().manual_seed(H * 100 + W)
+    img, gt = torch.rand(3, H, W, generator=g), torch.rand(3, H, W, generator=g)
+    mask = (torch.rand(1, H, W, generator=g) > 0.3).float() if use_mask else None
+    lam = 0.2
+    r_img, r_ssim, r_grad = _ref(img, gt, mask, lam, 1.0, 0.7)
+    x = img.clone().cuda().requires_grad_(True)
+    l_img, l_ssim = fused_photometric_loss(x, gt.cuda(), None if mask is None else mask.cuda(), lam)
+    (l_img + 0.7 * l_ssim).backward()
+    assert abs(float(l_img) - r_img) < 2e-6 and abs(float(l_ssim) - r_ssim) < 2e-6
+    assert rel_l1(x.grad, r_grad) <= 1e-4
+
+
+def test_fused_loss_on_reference_golden():
+    """Directly against the numbers the reference's own l1_loss / ssim produced (tests/golden/loss.npz)."""
+    from ggsplat.loss import fused_photometric_loss
+    d = np.load(os.path.join(G, "loss.npz"))
+    a, b, m = torch.tensor(d["img1"]).cuda(), torch.tensor(d["img2"]).cuda(), torch.tensor(d["mask"]).cuda()
+    for tag, mask in (("nomask", None), ("mask", m)):
+        x = a.clone().requires_grad_(True)
+        l_img, l_ssim = fused_photometric_loss(x, b, mask, 1.0)          # lambda = 1 isolates SSIM: l_ssim = 1 - ssim
+        assert abs((1.0 - float(l_ssim)) - float(d[f"ssim_{tag}"])) < 2e-6
+        (1.0 - l_ssim).backward()
+        assert rel_l1(x.grad, d[f"ssim_grad_{tag}"]) <= 1e-4
+        x = a.clone().requires_grad_(True)
+        l_img, l_ssim = fused_photometric_loss(x, b, mask, 0.0)          # lambda = 0 isolates L1
+        assert abs(float(l_img) - float(d[f"l1_{tag}"])) < 1e-6
+        l_img.backward()
+        assert rel_l1(x.grad, d[f"l1_grad_{tag}"]) <= 1e-6
+
+
+def test_fused_loss_batched_views_and_1080p_speed():
+    from ggsplat.loss import fused_photometric_loss, l1_loss, ssim
+    g = torch.Generator().manual_seed(1)
+    V, H, W = 3, 1080, 1920
+    img, gt = torch.rand(V, 3, H, W, generator=g).cuda(), torch.rand(V, 3, H, W, generator=g).cuda()
+    mask = (torch.rand(V, 1, H, W, generator=g) > 0.2).float().cuda()
+    x = img.clone().requires_grad_(True)
+    l_img, l_ssim = fused_photometric_loss(x, gt, mask, 0.2)
+    (l_img + l_ssim).sum().backward()
+    for v in range(V):                                       # per-view PyTorch composition on the GPU
+        y = img[v].clone().requires_grad_(True)
+        a = l1_loss(y, gt[v], mask[v]) * 0.8
+        b = 1.0 - ssim(y + 0, gt[v].clone(), mask[v]) * 0.2
+        (a + b).backward()
+        assert abs(float(a) - float(l_img[v])) < 2e-6 and abs(float(b) - float(l_ssim[v])) < 2e-6
+        assert rel_l1(x.grad[v], y.grad) <= 1e-4
+    # timing (informational, printed with -s): fused vs PyTorch composition, fwd+bwd per 1080p view
+    def timed(fn, n=5):
+        fn(); torch.cuda.synchronize(); t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+    def fused():
+        z = img[:1].clone().requires_grad_(True)
+        a, b = fused_photometric_loss(z, gt[:1], mask[:1], 0.2)
+        (a + b).sum().backward()
+    def torch_ops():
+        z = img[0].clone().requires_grad_(True)
+        (l1_loss(z, gt[0], mask[0]) * 0.8 + 1.0 - ssim(z + 0, gt[0].clone(), mask[0]) * 0.2).backward()
+    tf, tt = timed(fused), timed(torch_ops)
+    print(f"\\nphotometric loss fwd+bwd @1080p: fused {tf*1e3:.3f} ms, PyTorch ops {tt*1e3:.3f} ms ({tt/tf:.1f}x)")
+    assert tf < tt
