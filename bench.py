@@ -200,7 +200,7 @@ def main():
                                    "frac": round(B_view * views_per_sec / 1e9 / HBM_PEAK_GBS, 5)}}
 
         # ---- per-view drop-in loop (render() + autograd, one camera per call like the reference) ----
-        loop_vps = None
+        loop_vps = step_vps = None
         if args.loop_views > 0:
             from ggsplat.render import render
             from types import SimpleNamespace
@@ -223,6 +223,23 @@ def main():
             loop()
             torch.cuda.synchronize(dev)
             loop_vps = len(lcams) / (time.perf_counter() - t1)
+
+            # full s2 inner step per view: render + fused L1/SSIM loss + backward + Adam (ggsplat.inner_step)
+            from ggsplat.inner_step import DEFAULT_OPT, registration_step
+            model.training_setup(DEFAULT_OPT, is_ff=True)
+            gt_img = torch.rand(3, H, W, device=dev)
+            gt_mask = (torch.rand(1, H, W, device=dev) > 0.1).float()
+
+            def steps():
+                for c in lcams:
+                    registration_step(model, c, gt_img, gt_mask, bg, fused_loss=True)
+            steps()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            steps()
+            torch.cuda.synchronize(dev)
+            step_vps = len(lcams) / (time.perf_counter() - t1)
+            model.optimizer = None
 
         # ---- CPU baseline: the C oracle on the host cores, bounded sample of the same views ----
         cpu = None
@@ -259,6 +276,7 @@ def main():
                        "num_rendered_per_view": round(N_view, 1), "visible_per_view": round(P_vis, 1)},
             "roofline": roofline, "cpu_baseline": cpu,
             "per_view_loop_views_per_sec": None if loop_vps is None else round(loop_vps, 2),
+            "s2_inner_step_iters_per_sec": None if step_vps is None else round(step_vps, 2),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

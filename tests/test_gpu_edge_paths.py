@@ -1,0 +1,82 @@
+"""GPU paths that ordinary scenes never reach: per-tile lists longer than the LDS sort capacity (global
+bitonic fallback, length class 0), workgroup tile windows too large for the LDS histogram (direct-atomic
+fallback), binning-capacity overflow + retry, debug mode (sync + check after every kernel)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import REL_L1_TOL, cam_kwargs, rel_l1, seeded_image_weights, small_scene
+from ggsplat import synthetic as S
+from oracle.c_oracle import COracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _hip(sc, cam, bg, weights, debug=False):
+    from diff_gaussian_rasterization_depth_alpha import GaussianRasterizationSettings, GaussianRasterizer
+    dev = "cuda"
+    rs = GaussianRasterizationSettings(
+        image_height=cam.image_height, image_width=cam.image_width, tanfovx=math.tan(cam.FoVx * 0.5),
+        tanfovy=math.tan(cam.FoVy * 0.5), bg=torch.tensor(bg, device=dev), scale_modifier=1.0,
+        viewmatrix=cam.world_view_transform.to(dev), projmatrix=cam.full_proj_transform.to(dev),
+        sh_degree=sc["sh_degree"], campos=cam.camera_center.to(dev), prefiltered=False, debug=debug)
+    leaf = {k: sc[k].clone().to(dev).requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    m2d = torch.zeros(sc["means3D"].shape[0], 3, device=dev, requires_grad=True)
+    color, radii, depth, alpha = GaussianRasterizer(rs)(means3D=leaf["means3D"], means2D=m2d, opacities=leaf["opacities"],
+                                                        shs=leaf["shs"], scales=leaf["scales"], rotations=leaf["rotations"])
+    (color * weights[0].to(dev)).sum().backward()
+    return color.detach().cpu(), radii.cpu(), {k: v.grad.cpu() for k, v in leaf.items()}
+
+
+def _check(sc, cam, bg=(0.1, 0.2, 0.3), debug=False):
+    w = seeded_image_weights(cam.image_width, cam.image_height)
+    color, radii, grads = _hip(sc, cam, bg, w, debug=debug)
+    co = COracle(means3D=sc["means3D"], opacities=sc["opacities"], shs=sc["shs"], scales=sc["scales"],
+                 rotations=sc["rotations"], sh_degree=sc["sh_degree"], **cam_kwargs(cam, bg))
+    og = co.backward(w[0])
+    assert np.array_equal(radii.numpy(), co.radii)
+    assert rel_l1(color, co.color) <= REL_L1_TOL
+    for k, g in grads.items():
+        assert rel_l1(g.reshape(og[k].shape), og[k]) <= REL_L1_TOL, k
+    return co
+
+
+def test_tile_list_longer_than_lds_sort_capacity():
+    """6000 faint splats piled on one spot: tile lists of ~6000 > 4096 keys -> global-memory bitonic fallback."""
+    g = torch.Generator().manual_seed(0)
+    P = 6000
+    sc = S.random_gaussians(P, sh_degree=0, seed=1)
+    sc["means3D"] = torch.randn(P, 3, generator=g) * 0.01
+    sc["scales"] = torch.full((P, 3), 0.03)
+    sc["opacities"] = torch.full((P, 1), 0.02)                 # faint: nothing terminates, every splat is blended
+    cam = S.orbit_cameras(4, width=64, img_height=48, fx=70., fy=70., cx=31., cy=25.)[0]
+    co = _check(sc, cam)
+    assert int(np.diff(co.internals()["tile_start"]).max()) > 4096
+
+
+def test_workgroup_tile_window_too_large_for_lds():
+    """Randomly ordered splats over a 1080p frame: the 256 splats of a workgroup span > 2048 tiles, so the
+    histogram / scatter take the direct-global-atomic fallback."""
+    sc = S.random_gaussians(4096, sh_degree=1, seed=5)
+    sc["means3D"] = sc["means3D"] * torch.tensor([2.4, 1.3, 0.3])
+    sc["scales"] = sc["scales"] * 0.7
+    from ggsplat.cameras import look_at_camera
+    cam = look_at_camera((0.0, 0.0, -4.0), (0.0, 0.0, 0.0), width=1920, height=1080, fx=1500., fy=1500., cx=955.,
+                         cy=545., device="cpu")
+    co = _check(sc, cam)
+    assert (co.radii > 0).sum() > 3000
+
+
+def test_binning_capacity_overflow_retries(monkeypatch):
+    from ggsplat import rasterizer as R
+    sc, cam = small_scene(P=900, W=96, H=64, sh_degree=0, seed=12, scale_mul=8.0)
+    monkeypatch.setattr(R, "_cap_hint", {(0, 900, 96, 64, 1): 64})        # far too small: forces overflow + one retry
+    _check(sc, cam)
+    assert R._cap_hint[(0, 900, 96, 64, 1)] > 64
+
+
+def test_debug_mode_sync_after_each_kernel():
+    sc, cam = small_scene(P=500, W=80, H=48, sh_degree=2, seed=2, scale_mul=5.0)
+    _check(sc, cam, debug=True)
