@@ -42,6 +42,7 @@ _SIGS = {
     "ggs_photometric_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ggs_photometric_forward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 6),
     "ggs_photometric_backward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 7),
+    "ggs_dist2_3nn": (C.c_int, [C.c_int, _PTR, _PTR, _PTR]),
     "ggs_profile_enable": (C.c_int, [C.c_int]),
     "ggs_profile_read": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
     "ggs_last_error": (C.c_char_p, []),

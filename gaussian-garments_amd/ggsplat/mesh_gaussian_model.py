@@ -196,6 +196,30 @@ class MeshGaussianModel:
                                                              dim=-1, keepdim=True)
         self.denom[update_filter] += 1
 
+    # ---- persistence / initialisation ---------------------------------------
+    def save_ply(self, path: str):
+        """Local (mesh-frame) parameters in the reference's PLY layout (local_point_cloud.ply of
+        scene/mesh_gaussian_model.py:251-283; property order of scene/gaussian_model.py:179-209)."""
+        from .ply_io import save_gaussians
+        save_gaussians(path, self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling,
+                       self._rotation)
+
+    def load_ply(self, path: str):
+        """scene/gaussian_model.py:216-259: parameters become plain tensors (fixed while the mesh is optimised)."""
+        from .ply_io import load_gaussians
+        dev = self.mesh.v.device if self.mesh is not None else "cuda"
+        for k, v in load_gaussians(path, self.max_sh_degree, device=dev).items():
+            setattr(self, k, v)
+        self.active_sh_degree = self.max_sh_degree
+        self._bound = None
+
+    def init_scaling_from_neighbours(self, points: torch.Tensor) -> torch.Tensor:
+        """scales = log(sqrt(clamp_min(distCUDA2(points), 1e-7))) repeated on 3 axes
+        (scene/gaussian_model.py:135-136) through the HIP 3-NN kernel."""
+        from simple_knn._C import distCUDA2
+        dist2 = torch.clamp_min(distCUDA2(points.float()), 0.0000001)
+        return torch.log(torch.sqrt(dist2))[..., None].repeat(1, 3)
+
     def parameters(self):
         return [self.mesh.v, self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling,
                 self._rotation]

@@ -178,6 +178,13 @@ int ggs_photometric_forward(int n_views, int H, int W, const float* img, const f
 int ggs_photometric_backward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
                              const void* scratch, const float* weights, float* dL_dimg, void* stream);
 
+/*
+ * Mean squared distance of every point to its 3 nearest neighbours (self excluded) -- replaces
+ * `simple_knn._C.distCUDA2` (scene/gaussian_model.py:135, scene/mesh_gaussian_model.py:233).
+ * points [P][3], out [P].  Fewer than 4 points: the missing neighbours count as FLT_MAX like upstream.
+ */
+int ggs_dist2_3nn(int P, const float* points, float* out, void* stream);
+
 /* Profiling aid (bench.py roofline leg; not part of the reference's interface).  While enabled on the
  * calling thread, ggs_forward / ggs_backward bracket each kernel with hipEvents on `stream`, synchronise
  * once at the end of the call, and keep the per-kernel milliseconds of that call.  ggs_profile_read copies

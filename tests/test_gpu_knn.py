@@ -1,0 +1,50 @@
+"""distCUDA2 replacement (ggs_dist2_3nn) vs an exact KD-tree on the host: mean squared distance to the
+3 nearest neighbours, self excluded, duplicates at distance 0 counted."""
+import numpy as np
+import pytest
+import torch
+from scipy.spatial import cKDTree
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(pts):
+    d, _ = cKDTree(pts.astype(np.float64)).query(pts.astype(np.float64), k=4)
+    return (d[:, 1:] ** 2).mean(1)
+
+
+@pytest.mark.parametrize("P", [4, 257, 5000, 100000])
+def test_dist2_matches_kdtree(P):
+    from simple_knn._C import distCUDA2
+    g = torch.Generator().manual_seed(P)
+    pts = torch.randn(P, 3, generator=g)
+    out = distCUDA2(pts.cuda()).cpu().numpy()
+    ref = _ref(pts.numpy())
+    assert np.allclose(out, ref, rtol=2e-5, atol=1e-9)
+
+
+def test_duplicates_and_model_init():
+    from simple_knn._C import distCUDA2
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    pts = torch.tensor([[0.0, 0, 0], [0.0, 0, 0], [1.0, 0, 0], [0.0, 2, 0], [5.0, 5, 5]])
+    out = distCUDA2(pts.cuda()).cpu()
+    assert abs(float(out[0]) - (0 + 1 + 4) / 3) < 1e-6          # its duplicate is a neighbour at distance 0
+    m = MeshGaussianModel(0)
+    sc = m.init_scaling_from_neighbours(pts.cuda())
+    assert sc.shape == (5, 3) and torch.allclose(sc[:, 0], torch.log(torch.sqrt(out.clamp_min(1e-7))).cuda())
+
+
+def test_ply_round_trip_through_model(tmp_path):
+    from ggsplat import synthetic as S
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    v, f = S.skirt_mesh(12, 6)
+    p = S.skirt_gaussian_params(f.shape[0], sh_degree=2)
+    m = MeshGaussianModel.from_tensors(v, f, p, sh_degree=2, device="cuda")
+    path = str(tmp_path / "point_cloud" / "frame_00000" / "local_point_cloud.ply")
+    m.save_ply(path)
+    m2 = MeshGaussianModel.from_tensors(v, f, S.skirt_gaussian_params(f.shape[0], sh_degree=2, seed=9), sh_degree=2, device="cuda")
+    m2.load_ply(path)
+    for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
+        assert torch.equal(getattr(m2, k).cpu(), getattr(m, k).detach().cpu()), k
+    m.update_face_coor(); m2.update_face_coor()
+    assert torch.equal(m.get_xyz, m2.get_xyz) and torch.equal(m.get_rotation, m2.get_rotation)
