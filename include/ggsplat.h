@@ -185,6 +185,23 @@ int ggs_photometric_backward(int n_views, int H, int W, const float* img, const 
  */
 int ggs_dist2_3nn(int P, const float* points, float* out, void* stream);
 
+/*
+ * StyleGAN2 ops of the appearance network -- what the reference's extension modules `fused` and
+ * `upfirdn2d` (scene/styleunet/fused_act.py:30, upfirdn2d.py:30; CUDA sources under scene/styleunet/) export.
+ *   ggs_fused_bias_act: y[i] = act(x[i] + bias[(i / step_b) % size_b]) * scale, n elements, bias / ref may be NULL;
+ *       act 1 linear, 3 leaky ReLU(alpha); grad 0 forward, 1 derivative gated by sign(ref), 2 zero.
+ *   ggs_upfirdn2d: input [major][in_h][in_w][minor], kernel [kh][kw] -> out [major][out_h][out_w][minor]
+ *       (upsample by zero insertion, pad (negative = crop), convolve, decimate);
+ *       out_h = (in_h up_y + pad_y0 + pad_y1 - kh + down_y) / down_y, likewise out_w (ggs_upfirdn2d_out_size).
+ */
+int ggs_fused_bias_act(size_t n, const float* x, const float* bias, const float* ref, int step_b, int size_b,
+                       int act, int grad, float alpha, float scale, float* y, void* stream);
+int ggs_upfirdn2d_out_size(int in_h, int in_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,
+                           int pad_x1, int pad_y0, int pad_y1, int* out_h, int* out_w);
+int ggs_upfirdn2d(int major, int in_h, int in_w, int minor, const float* input, const float* kernel, int kh, int kw,
+                  int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                  float* out, void* stream);
+
 /* Profiling aid (bench.py roofline leg; not part of the reference's interface).  While enabled on the
  * calling thread, ggs_forward / ggs_backward bracket each kernel with hipEvents on `stream`, synchronise
  * once at the end of the call, and keep the per-kernel milliseconds of that call.  ggs_profile_read copies

@@ -88,6 +88,55 @@ def loss_golden():
     np.savez(os.path.join(OUT, "loss.npz"), **rec)
 
 
+
+
+def stylegan_golden():
+    """fused_leaky_relu (CPU branch of scene/styleunet/fused_act.py:118-129) and upfirdn2d_native
+    (scene/styleunet/upfirdn2d.py:186-227): the reference's own PyTorch paths for its two CUDA ops.  Both modules
+    import the compiled extensions at import time, so empty stand-in modules are registered first (they are never
+    called: only the native / CPU code paths run)."""
+    import types
+    for name in ("fused", "upfirdn2d"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    import importlib.util
+
+    def load(modname, path):
+        spec = importlib.util.spec_from_file_location(modname, path)
+        m = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(m)
+        return m
+    fa = load("ref_fused_act", os.path.join(REF, "scene/styleunet/fused_act.py"))
+    up = load("ref_upfirdn2d", os.path.join(REF, "scene/styleunet/upfirdn2d.py"))
+    g = torch.Generator().manual_seed(4)
+    rec = {}
+    x = torch.randn(2, 6, 5, 7, generator=g)
+    b = torch.randn(6, generator=g)
+    rec["act_x"], rec["act_b"] = x.numpy(), b.numpy()
+    rec["act_y_bias"] = fa.fused_leaky_relu(x, b).numpy()
+    rec["act_y_nobias"] = fa.fused_leaky_relu(x, None).numpy()
+    x2 = torch.randn(3, 10, generator=g)
+    b2 = torch.randn(10, generator=g)
+    rec["act2_x"], rec["act2_b"], rec["act2_y"] = x2.numpy(), b2.numpy(), fa.fused_leaky_relu(x2, b2).numpy()
+    k4 = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k4 = k4[None, :] * k4[:, None]
+    k4 = k4 / k4.sum()
+    k3 = torch.randn(3, 3, generator=g)
+    k2 = torch.tensor([[1.0, 1.0], [1.0, -1.0]]) / 2
+    k23 = torch.randn(2, 3, generator=g)
+    cases = [  # (kernel, up, down, pad(x0,x1,y0,y1))  -- the StyleUNet configurations + stress cases
+        ("blur", k4, (1, 1), (1, 1), (2, 1, 2, 1)), ("blur3", k3, (1, 1), (1, 1), (1, 1, 1, 1)),
+        ("up2", k4 * 4, (2, 2), (1, 1), (2, 1, 2, 1)), ("up2haar", k2, (2, 2), (1, 1), (1, 0, 1, 0)),
+        ("down2", k4, (1, 1), (2, 2), (1, 1, 1, 1)), ("down2haar", k2, (1, 1), (2, 2), (0, 0, 0, 0)),
+        ("crop", k3, (1, 1), (1, 1), (-1, 2, 0, -1)), ("mixed", k23, (3, 2), (2, 3), (2, 0, 1, 3))]
+    inp = torch.randn(2, 3, 9, 11, generator=g)
+    rec["ufd_in"] = inp.numpy()
+    for name, k, u, d, p in cases:
+        rec[f"ufd_{name}_k"] = k.numpy()
+        rec[f"ufd_{name}_cfg"] = np.array([*u, *d, *p])
+        rec[f"ufd_{name}_out"] = up.upfirdn2d_native(inp, k, u[0], u[1], d[0], d[1], *p).numpy()
+    np.savez(os.path.join(OUT, "stylegan_ops.npz"), **rec)
+
+
 if __name__ == "__main__":
-    sh_golden(); camera_golden(); face_golden(); loss_golden()
+    sh_golden(); camera_golden(); face_golden(); loss_golden(); stylegan_golden()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))

@@ -1,0 +1,83 @@
+"""HIP `fused.fused_bias_act` and `upfirdn2d.upfirdn2d` (drop-ins for the reference's StyleGAN2 extension
+modules) against golden outputs of the reference's own PyTorch paths (fused_act.py CPU branch,
+upfirdn2d_native), plus the derivative modes and the adjoint identity the reference's autograd wrappers rely on."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+D = np.load(os.path.join(os.path.dirname(__file__), "golden", "stylegan_ops.npz"))
+SQRT2 = 2 ** 0.5
+
+
+def test_fused_bias_act_forward_matches_reference():
+    import fused
+    x, b = torch.tensor(D["act_x"]).cuda(), torch.tensor(D["act_b"]).cuda()
+    e = x.new_empty(0)
+    y = fused.fused_bias_act(x, b, e, 3, 0, 0.2, SQRT2)
+    assert np.allclose(y.cpu().numpy(), D["act_y_bias"], rtol=1e-6, atol=1e-7)
+    y = fused.fused_bias_act(x, e, e, 3, 0, 0.2, SQRT2)
+    assert np.allclose(y.cpu().numpy(), D["act_y_nobias"], rtol=1e-6, atol=1e-7)
+    x2, b2 = torch.tensor(D["act2_x"]).cuda(), torch.tensor(D["act2_b"]).cuda()        # 2-D input: step_b = 1
+    assert np.allclose(fused.fused_bias_act(x2, b2, e, 3, 0, 0.2, SQRT2).cpu().numpy(), D["act2_y"], rtol=1e-6, atol=1e-7)
+    # linear act, half precision round trip
+    yl = fused.fused_bias_act(x.half(), b.half(), e.half(), 1, 0, 0.2, 0.5)
+    assert yl.dtype == torch.float16 and torch.allclose(yl.float(), ((x.half() + b.half().view(1, -1, 1, 1)).float() * 0.5), atol=2e-3)
+
+
+def test_fused_bias_act_derivative_modes():
+    """grad=1 (what FusedLeakyReLUFunctionBackward calls) equals autograd of the forward; grad=2 is zero."""
+    import fused
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3, 5, 4, 4, generator=g).cuda().requires_grad_(True)
+    b = torch.randn(5, generator=g).cuda()
+    ref = torch.nn.functional.leaky_relu(x + b.view(1, -1, 1, 1), 0.2) * SQRT2
+    go = torch.randn(ref.shape, generator=g).cuda()
+    (gx,) = torch.autograd.grad(ref, x, go)
+    e = x.new_empty(0)
+    out = fused.fused_bias_act(x.detach(), b, e, 3, 0, 0.2, SQRT2)
+    gi = fused.fused_bias_act(go, e, out, 3, 1, 0.2, SQRT2)
+    assert torch.allclose(gi, gx, rtol=1e-6, atol=1e-7)
+    assert float(fused.fused_bias_act(go, e, out, 3, 2, 0.2, SQRT2).abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("name", ["blur", "blur3", "up2", "up2haar", "down2", "down2haar", "crop", "mixed"])
+def test_upfirdn2d_matches_reference_native(name):
+    import upfirdn2d as U
+    inp = torch.tensor(D["ufd_in"]).cuda()                     # [2,3,9,11]
+    k = torch.tensor(D[f"ufd_{name}_k"]).cuda()
+    ux, uy, dx, dy, px0, px1, py0, py1 = [int(v) for v in D[f"ufd_{name}_cfg"]]
+    B, Cn, Hh, Ww = inp.shape
+    out = U.upfirdn2d(inp.reshape(-1, Hh, Ww, 1), k, ux, uy, dx, dy, px0, px1, py0, py1)
+    ref = D[f"ufd_{name}_out"]
+    assert tuple(out.shape) == (B * Cn, ref.shape[2], ref.shape[3], 1)
+    assert np.allclose(out.view(B, Cn, ref.shape[2], ref.shape[3]).cpu().numpy(), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_upfirdn2d_adjoint_identity_and_minor():
+    """The reference's backward is upfirdn2d(grad, flip(kernel), up<->down, g_pad) (upfirdn2d.py:128-141):
+    check <upfirdn(x), y> == <x, backward(y)> with those parameters, and the minor (channels-last) axis."""
+    import upfirdn2d as U
+    g = torch.Generator().manual_seed(1)
+    k = torch.randn(4, 3, generator=g).cuda()
+    up, down, pad = (2, 1), (1, 2), (2, 1, 1, 2)
+    x = torch.randn(5, 8, 6, 1, generator=g).cuda()
+    out = U.upfirdn2d(x, k, up[0], up[1], down[0], down[1], *pad)
+    y = torch.randn(out.shape, generator=g).cuda()
+    kh, kw = k.shape
+    in_h, in_w = 8, 6
+    out_h, out_w = out.shape[1], out.shape[2]
+    g_pad_x0, g_pad_y0 = kw - pad[0] - 1, kh - pad[2] - 1
+    g_pad_x1 = in_w * up[0] - out_w * down[0] + pad[0] - up[0] + 1
+    g_pad_y1 = in_h * up[1] - out_h * down[1] + pad[2] - up[1] + 1
+    gx = U.upfirdn2d(y, torch.flip(k, [0, 1]), down[0], down[1], up[0], up[1], g_pad_x0, g_pad_x1, g_pad_y0, g_pad_y1)
+    assert gx.shape == x.shape
+    lhs, rhs = float((out.double() * y.double()).sum()), float((x.double() * gx.double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+    xm = torch.randn(2, 7, 5, 3, generator=g).cuda()           # minor = 3 processed independently
+    om = U.upfirdn2d(xm, k, 1, 1, 1, 1, 1, 1, 2, 0)
+    for c in range(3):
+        oc = U.upfirdn2d(xm[..., c:c + 1].contiguous(), k, 1, 1, 1, 1, 1, 1, 2, 0)
+        assert torch.equal(om[..., c:c + 1], oc)
