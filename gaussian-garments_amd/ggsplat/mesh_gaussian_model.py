@@ -71,6 +71,25 @@ def mesh_bind(verts, faces, binding, local_xyz, log_scaling, raw_rot, bary=None)
                            None if bary is None else bary.contiguous().float())
 
 
+def visible_mask(verts, faces, binding, targets, camera, return_first_hit: bool = False):
+    """First-hit ray cast camera -> targets against the mesh on the GPU (ggs_visibility)."""
+    if verts.device.type != "cuda":
+        raise RuntimeError("ggsplat visibility runs on the GPU only (no CPU path in the product)")
+    L = lib()
+    dev = verts.device
+    v, f = verts.detach().float().contiguous(), faces.long().contiguous()
+    tg, bd = targets.detach().float().contiguous(), binding.long().contiguous()
+    cam = camera.detach().float().reshape(3).to(dev).contiguous()
+    P, Fn, Vn = tg.shape[0], f.shape[0], v.shape[0]
+    cap = 32 * Fn + 65536
+    scratch = torch.empty(L.ggs_visibility_scratch_bytes(Fn, Vn, cap), device=dev, dtype=torch.uint8)
+    mask = torch.empty(P, device=dev, dtype=torch.uint8)
+    first = torch.empty(P, device=dev, dtype=torch.int32) if return_first_hit else None
+    check(L.ggs_visibility(P, Fn, Vn, ptr(v), ptr(f), ptr(cam), ptr(tg), ptr(bd), ptr(scratch), cap, ptr(mask), ptr(first),
+                           _stream(dev)), "ggs_visibility")
+    return (mask.bool(), first) if return_first_hit else mask.bool()
+
+
 class MeshGaussianModel:
     def __init__(self, sh_degree: int):
         self.active_sh_degree = 0
@@ -195,6 +214,23 @@ class MeshGaussianModel:
         self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2],
                                                              dim=-1, keepdim=True)
         self.denom[update_filter] += 1
+
+    # ---- visibility -------------------------------------------------------------
+    def get_anchor_points(self) -> torch.Tensor:
+        """The point of each Gaussian ON its bound face: the face centre, or the barycentric point when `gs_bc`
+        is set (AvatarGaussianModel.get_barycentric_3d, scene/avatar_gaussian_model.py:153-159)."""
+        P = self._xyz.shape[0]
+        dev = self.mesh.v.device
+        with torch.no_grad():
+            return mesh_bind(self.mesh.v, self.mesh.f, self.binding, torch.zeros(P, 3, device=dev), self._scaling,
+                             self._rotation, self.gs_bc)[0]
+
+    def get_visible_mask(self, camera: torch.Tensor, return_first_hit: bool = False):
+        """camera [3] (GPU) -> bool [P]: the first mesh triangle hit by the ray camera -> anchor is the Gaussian's own
+        face.  Same semantics as scene/avatar_gaussian_model.py:227-263, but on the device (no open3d, no host
+        round trip)."""
+        return visible_mask(self.mesh.v.detach(), self.mesh.f, self.binding, self.get_anchor_points(), camera,
+                            return_first_hit)
 
     # ---- persistence / initialisation (SURVEY.md section 8f #2) ---------------------------------------
     def save_ply(self, path: str):

@@ -202,6 +202,20 @@ int ggs_upfirdn2d(int major, int in_h, int in_w, int minor, const float* input, 
                   int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
                   float* out, void* stream);
 
+/*
+ * Visibility of mesh-bound Gaussians from one camera -- replaces the per-iteration open3d / Embree
+ * ray cast of AvatarGaussianModel.get_visible_mask (scene/avatar_gaussian_model.py:227-263): ray i goes from
+ * `cam` [3] (device) to targets[i] (the Gaussian's anchor on its face); mask[i] = 1 iff the FIRST triangle the
+ * ray hits is binding[i].  first_hit [P] (or NULL) receives that triangle id (-1: no hit).
+ * verts [n_verts][3], faces [F][3] int64, binding [P] int64.  scratch: ggs_visibility_scratch_bytes(F, n_verts,
+ * ids_capacity); ids_capacity bounds the triangle-in-cell lists of the camera-space grid (32 F is plenty); if it
+ * is exceeded the call falls back to testing every triangle on the device -- slower, same answer, no host sync.
+ */
+size_t ggs_visibility_scratch_bytes(int F, int n_verts, size_t ids_capacity);
+int ggs_visibility(int P, int F, int n_verts, const float* verts, const int64_t* faces, const float* cam,
+                   const float* targets, const int64_t* binding, void* scratch, size_t ids_capacity,
+                   unsigned char* mask, int* first_hit, void* stream);
+
 /* Profiling aid (bench.py roofline leg; not part of the reference's interface).  While enabled on the
  * calling thread, ggs_forward / ggs_backward bracket each kernel with hipEvents on `stream`, synchronise
  * once at the end of the call, and keep the per-kernel milliseconds of that call.  ggs_profile_read copies
