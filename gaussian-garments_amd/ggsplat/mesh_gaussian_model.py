@@ -164,6 +164,20 @@ class MeshGaussianModel:
     def get_opacity(self):
         return self.opacity_activation(self._opacity)
 
+    def get_covariance(self, scaling_modifier=1):
+        """Python cov3D path of render() (pipe.compute_cov3D_python): Sigma = L L^T with
+        L = R(normalise(_rotation)) diag(modifier * get_scaling), stripped to (xx,xy,xz,yy,yz,zz) --
+        scene/gaussian_model.py:27-31,118-119 + utils/general_utils.py:74-120.  Like the reference it uses the
+        LOCAL rotation `_rotation`, not the mesh-bound one (SURVEY a11 caveat); s2 / s3 never enable this path."""
+        q = torch.nn.functional.normalize(self._rotation)
+        r, x, y, z = q.unbind(-1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                         2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                         2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).view(-1, 3, 3)
+        Lm = R * (scaling_modifier * self.get_scaling)[:, None, :]
+        S = Lm @ Lm.transpose(1, 2)
+        return torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1)
+
     @property
     def get_features(self):
         return torch.cat((self._features_dc, self._features_rest), dim=1)

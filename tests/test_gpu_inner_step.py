@@ -147,3 +147,31 @@ def test_appearance_step_matches_oracle_pipeline():
         assert rel_l1(getattr(model, n).grad, leaf[n].grad) <= TOL, n
     assert rel_l1(model.mesh.v.grad, mv.grad) <= TOL
     assert rel_l1(wg.grad, wc.grad) <= TOL
+
+
+def test_render_python_paths_and_doll_render_on_gpu():
+    """render() with pipe.compute_cov3D_python / convert_SHs_python (precomputed cov3D and colours go through the
+    other two input modes of the HIP forward) and the forward-only doll_render of inference.py."""
+    from types import SimpleNamespace as NS
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    from ggsplat.render import doll_render, render
+    v, f, params, cams, gt, mask = _scene(sh_degree=1, seed=6)
+    params["_rotation"] = torch.tensor([1.0, 0, 0, 0]).repeat(f.shape[0], 1)
+    model = MeshGaussianModel.from_tensors(v, f, params, sh_degree=1, device="cuda")
+    model.update_face_coor()
+    cam = cams[1]
+    for n in ("world_view_transform", "full_proj_transform", "camera_center"):
+        setattr(cam, n, getattr(cam, n).cuda())
+    bg = torch.tensor([0.1, 0.1, 0.1], device="cuda")
+    base = render(cam, model, NS(debug=False, compute_cov3D_python=False, convert_SHs_python=False), bg)
+    # SH evaluated in Python == SH evaluated in the kernel (cross-stage identity through the product's eval_sh)
+    py_sh = render(cam, model, NS(debug=False, compute_cov3D_python=False, convert_SHs_python=True), bg)
+    assert rel_l1(py_sh["render"], base["render"]) <= 1e-5 and torch.equal(py_sh["radii"], base["radii"])
+    # cov3D python path runs (it uses the LOCAL rotation like the reference, so only shapes / finiteness are checked)
+    py_cov = render(cam, model, NS(debug=False, compute_cov3D_python=True, convert_SHs_python=False), bg)
+    assert py_cov["render"].shape == (3, H, W) and bool(torch.isfinite(py_cov["render"]).all())
+    with torch.no_grad():
+        doll = NS(xyz=model.get_xyz, opacity=model.get_opacity, scaling=model.get_scaling, rotation=model.get_rotation,
+                  features=model.get_features, active_sh_degree=1)
+        img, depth, alpha = doll_render(cam, doll, NS(debug=False), bg)
+    assert torch.equal(img, base["render"]) and alpha.shape == (1, H, W) and depth.shape == (1, H, W)
