@@ -107,6 +107,9 @@ int bwd_splits(const GgsParams* p) {
     return s < 1 ? 1 : (s > p->n_views ? p->n_views : s);
 }
 
+// launches with fewer (view, tile) work items than this use the one-wave-per-quadrant render kernels
+#define GGS_QUAD_ITEMS 24576
+
 struct Dims { int gx, gy, T; };
 Dims dims(const GgsParams* p) {
     Dims d;
@@ -260,7 +263,9 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
         a.rec = (const SplatRec*)geom; a.bg = bg; a.out_color = out_color; a.out_depth = out_depth;
         a.out_alpha = out_alpha; a.final_T = final_T; a.n_contrib = n_contrib;
         prof_start(K_RENDER_FWD, s);
-        hipLaunchKernelGGL(ggs_k_render_fwd, dim3((unsigned)n_items), dim3(64), 0, s, a);
+        // small launches (a single view): one wave per (tile, quadrant) shortens the serial chain of the longest tile
+        if (n_items < GGS_QUAD_ITEMS) hipLaunchKernelGGL(ggs_k_render_fwd_quad, dim3((unsigned)n_items * 4), dim3(64), 0, s, a);
+        else hipLaunchKernelGGL(ggs_k_render_fwd, dim3((unsigned)n_items), dim3(64), 0, s, a);
         prof_stop(K_RENDER_FWD, s);
         GGS_TRY(check("render_fwd", s, p->debug));
     }
@@ -328,7 +333,12 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
         a.acc = (GradRec*)scratch;
         const dim3 gridT((unsigned)(V * d.T));   // one wave64 per (view, tile) work item, longest lists first
         prof_start(K_RENDER_BWD, s);
-        if (dL_ddepth || dL_dalpha) hipLaunchKernelGGL(ggs_k_render_bwd_da, gridT, dim3(64), 0, s, a);
+        const bool da = dL_ddepth || dL_dalpha;
+        if (a.n_items < GGS_QUAD_ITEMS) {
+            const dim3 gridQ((unsigned)(a.n_items * 4));
+            if (da) hipLaunchKernelGGL(ggs_k_render_bwd_da_quad, gridQ, dim3(64), 0, s, a);
+            else hipLaunchKernelGGL(ggs_k_render_bwd_quad, gridQ, dim3(64), 0, s, a);
+        } else if (da) hipLaunchKernelGGL(ggs_k_render_bwd_da, gridT, dim3(64), 0, s, a);
         else hipLaunchKernelGGL(ggs_k_render_bwd, gridT, dim3(64), 0, s, a);
         prof_stop(K_RENDER_BWD, s);
         GGS_TRY(check("render_bwd", s, p->debug));

@@ -107,8 +107,11 @@ __global__ void ggs_k_order_tiles(OrderArgs a);
 __global__ void ggs_k_sort_tiles(SortArgs a);
 __global__ void ggs_k_sort_tiles_wave(SortArgs a);
 __global__ void ggs_k_render_fwd(RenderArgs a);
+__global__ void ggs_k_render_fwd_quad(RenderArgs a);
 __global__ void ggs_k_render_bwd(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_da(RenderBwdArgs a);
+__global__ void ggs_k_render_bwd_quad(RenderBwdArgs a);
+__global__ void ggs_k_render_bwd_da_quad(RenderBwdArgs a);
 __global__ void ggs_k_preprocess_bwd_sh0(PreBwdArgs a);
 __global__ void ggs_k_preprocess_bwd_sh1(PreBwdArgs a);
 __global__ void ggs_k_preprocess_bwd_sh2(PreBwdArgs a);

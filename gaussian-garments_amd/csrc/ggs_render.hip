@@ -80,10 +80,17 @@ __device__ __forceinline__ Rec3 gather_round(const float4* __restrict__ rec, con
 
 }  // namespace
 
-// K4b: grid V*T work items, block 64 (one wave per tile).
-__global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) {
+namespace {
+
+// K4b body.  NQ = 4: one wave per tile, lane = 4 pixels (one per quadrant) -- the throughput mapping.
+// NQ = 1: one wave per (tile, quadrant), grid 4x larger -- the latency mapping for launches too small to fill
+// the chip (a single view has ~1.2k non-empty tiles for 1024 SIMDs and is bounded by the serial walk of its
+// longest tile; splitting the tile over 4 waves shortens that chain ~3x).  Same arithmetic, same results.
+template <int NQ>
+__device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
     if (a.header->overflow) return;
-    const uint32_t item = a.order[blockIdx.x];       // (view, tile) work items, longest lists first
+    const uint32_t item = a.order[NQ == 4 ? blockIdx.x : blockIdx.x >> 2];   // work items, longest lists first
+    const int q0 = NQ == 4 ? 0 : (int)(blockIdx.x & 3);
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
     const int tx = t % a.gx, ty = t / a.gx;
     const int ox = tx * GGS_TILE, oy = ty * GGS_TILE;
@@ -93,12 +100,12 @@ __global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) {
     uint32_t* ids = a.ids + base;
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
 
-    float pxf[4], pyf[4], T[4], C0[4], C1[4], C2[4], D[4], A[4];
-    uint32_t last[4];
-    bool done[4], inside[4];
+    float pxf[NQ], pyf[NQ], T[NQ], C0[NQ], C1[NQ], C2[NQ], D[NQ], A[NQ];
+    uint32_t last[NQ];
+    bool done[NQ], inside[NQ];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
+    for (int q = 0; q < NQ; ++q) {
+        const int px = px0 + ((q0 + q) & 1) * 8, py = py0 + ((q0 + q) >> 1) * 8;
         inside[q] = px < a.W && py < a.H;
         done[q] = !inside[q];
         pxf[q] = (float)px; pyf[q] = (float)py;
@@ -108,8 +115,14 @@ __global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) {
 
     if (L > 0) {
         Rec3 nxt = gather_round(rec, ids, 0, L, lane);
+        auto all_done = [&]() {
+            bool d = true;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) d = d && done[q];
+            return __all(d);
+        };
         for (int first = 0; first < L; first += 64) {
-            if (__all(done[0] && done[1] && done[2] && done[3])) break;
+            if (all_done()) break;
             const Rec3 cur = nxt;
             if (first + 64 < L) nxt = gather_round(rec, ids, first + 64, L, lane);
             const int n = min(64, L - first);
@@ -126,8 +139,8 @@ __global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) {
                 const float dep = bcast(cur.c.y, j);
                 const uint32_t pos = (uint32_t)(first + j + 1);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    if (!(word & (1u << (GGS_ID_BITS + q)))) continue;   // wave-uniform: one scalar branch
+                for (int q = 0; q < NQ; ++q) {
+                    if (!(word & (1u << (GGS_ID_BITS + q0 + q)))) continue;   // wave-uniform: one scalar branch
                     // predicated, branch-free per-pixel update: lane masks instead of nested exec juggling
                     const float dx = gx - pxf[q], dy = gy - pyf[q];
                     const float power = -0.5f * (cxx * dx * dx + cyy * dy * dy) - cxy * dx * dy;
@@ -146,12 +159,18 @@ __global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) {
                     A[q] += w;
                     T[q] = app ? test_T : T[q];
                     last[q] = app ? pos : last[q];
-                    if (__any(app)) blended |= 1u << (GGS_ID_BITS + q);
+                    if (__any(app)) blended |= 1u << (GGS_ID_BITS + q0 + q);
                 }
-                if (lane == j) neww |= blended;
-                if ((j & 15) == 15 && __all(done[0] && done[1] && done[2] && done[3])) break;
+                if (NQ == 4) {
+                    if (lane == j) neww |= blended;
+                } else {
+                    // four waves share the word: each clears only its own quadrant bit, atomically
+                    const uint32_t mine = 1u << (GGS_ID_BITS + q0);
+                    if ((word & mine) && !blended && lane == 0) atomicAnd(&ids[first + j], ~mine);
+                }
+                if ((j & 15) == 15 && all_done()) break;
             }
-            if (lane < n) ids[first + lane] = neww;
+            if (NQ == 4 && lane < n) ids[first + lane] = neww;
         }
     }
 
@@ -160,9 +179,9 @@ __global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) {
     const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
     float* oc = a.out_color + (size_t)v * 3 * HW;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         if (!inside[q]) continue;
-        const size_t pix = (size_t)(py0 + (q >> 1) * 8) * a.W + (px0 + (q & 1) * 8);
+        const size_t pix = (size_t)(py0 + ((q0 + q) >> 1) * 8) * a.W + (px0 + ((q0 + q) & 1) * 8);
         a.final_T[(size_t)v * HW + pix] = T[q];
         a.n_contrib[(size_t)v * HW + pix] = last[q];
         oc[pix] = fmaf(T[q], bg0, C0[q]);
@@ -173,12 +192,19 @@ __global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) {
     }
 }
 
+}  // namespace
+
+// K4b: grid V*T work items (x4 for the per-quadrant variant), block 64.
+__global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) { render_fwd_body<4>(a); }
+__global__ __launch_bounds__(64) void ggs_k_render_fwd_quad(RenderArgs a) { render_fwd_body<1>(a); }
+
 namespace {
 
 // K5 body.  DA: gradients of the depth / alpha outputs are present.
-template <bool DA>
+template <bool DA, int NQ>
 __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
-    const uint32_t item = a.order[blockIdx.x];       // (view, tile) work items, longest lists first
+    const uint32_t item = a.order[NQ == 4 ? blockIdx.x : blockIdx.x >> 2];   // work items, longest lists first
+    const int q0 = NQ == 4 ? 0 : (int)(blockIdx.x & 3);                      // NQ = 1: one wave per quadrant
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
     const int L = (int)a.tile_count[(size_t)v * a.T + t];
     if (L == 0) return;
@@ -200,12 +226,14 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
     // because dL/dalpha_j = T_j s_j - B / (1 - alpha_j).  This is the upstream recurrence
     // (accum_rec / last_alpha / last_color + the background term) folded into one scalar:
     // accum_rec_j = (sum_{k>j} c_k w_k) / (T_j (1 - alpha_j)).
-    float pxf[4], pyf[4], T[4], B[4], dC0[4], dC1[4], dC2[4], dD[4], dA[4];
-    int nc[4];
+    float pxf[NQ], pyf[NQ], T[NQ], B[NQ], dC0[NQ], dC1[NQ], dC2[NQ], dD[NQ], dA[NQ];
+    int nc[NQ];
     int maxc = 0;
+    uint32_t my_bits = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
+    for (int q = 0; q < NQ; ++q) {
+        my_bits |= 1u << (GGS_ID_BITS + q0 + q);
+        const int px = px0 + ((q0 + q) & 1) * 8, py = py0 + ((q0 + q) >> 1) * 8;
         const bool inside = px < a.W && py < a.H;
         const size_t pix = (size_t)py * a.W + px;
         pxf[q] = (float)px; pyf[q] = (float)py;
@@ -243,7 +271,7 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
         for (int j = n - 1; j >= 0; --j) {
             const int pos = first + j;                  // list position; pixel q blended it iff pos < nc[q]
             const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, j);
-            if (!(word >> GGS_ID_BITS)) continue;       // the forward blended this splat nowhere in the tile
+            if (!(word & my_bits)) continue;            // the forward blended this splat nowhere in this wave's pixels
             const float gx = bcast(cur.a.x, j), gy = bcast(cur.a.y, j);
             const float cxx = bcast(cur.a.z, j), cxy = bcast(cur.a.w, j), cyy = bcast(cur.b.x, j);
             const float op = bcast(cur.b.y, j);
@@ -252,8 +280,8 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
             float v_mx = 0.f, v_my = 0.f, v_cx = 0.f, v_cy = 0.f, v_cz = 0.f, v_op = 0.f;
             float v_r = 0.f, v_g = 0.f, v_b = 0.f, v_dep = 0.f;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                if (!(word & (1u << (GGS_ID_BITS + q)))) continue;   // quadrant did not blend it (forward's mask)
+            for (int q = 0; q < NQ; ++q) {
+                if (!(word & (1u << (GGS_ID_BITS + q0 + q)))) continue;   // quadrant did not blend it (forward's mask)
                 const float dx = gx - pxf[q], dy = gy - pyf[q];
                 const float power = -0.5f * (cxx * dx * dx + cyy * dy * dy) - cxy * dx * dy;
                 const float Gr = __expf(power);
@@ -298,7 +326,9 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
 
 }  // namespace
 
-// K5: grid V*T work items, block 64 (one wave per tile).  Two entry points so the common case (no loss on depth /
-// alpha: s2_registration.py:258-267, s3_appearance.py:131-140) carries no dead work.
-__global__ __launch_bounds__(64) void ggs_k_render_bwd(RenderBwdArgs a) { render_bwd_body<false>(a); }
-__global__ __launch_bounds__(64) void ggs_k_render_bwd_da(RenderBwdArgs a) { render_bwd_body<true>(a); }
+// K5: grid V*T work items (x4 for the per-quadrant variant), block 64.  Separate entry points so the common case
+// (no loss on depth / alpha: s2_registration.py:258-267, s3_appearance.py:131-140) carries no dead work.
+__global__ __launch_bounds__(64) void ggs_k_render_bwd(RenderBwdArgs a) { render_bwd_body<false, 4>(a); }
+__global__ __launch_bounds__(64) void ggs_k_render_bwd_da(RenderBwdArgs a) { render_bwd_body<true, 4>(a); }
+__global__ __launch_bounds__(64) void ggs_k_render_bwd_quad(RenderBwdArgs a) { render_bwd_body<false, 1>(a); }
+__global__ __launch_bounds__(64) void ggs_k_render_bwd_da_quad(RenderBwdArgs a) { render_bwd_body<true, 1>(a); }
