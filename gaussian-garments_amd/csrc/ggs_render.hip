@@ -5,12 +5,12 @@
 // quadrant q of the tile (x = 8(q&1) + (l&7), y = 8(q>>1) + (l>>3)), so a quadrant a splat
 // does not reach is skipped with a single exec-mask branch, exactly like a 4-wave block
 // would skip a wave -- but the per-splat overhead (record fetch, loop, reduction) is paid
-// once per tile instead of four times, and there is no LDS staging and no barrier at all:
+// once per tile instead of four times, and there is no workgroup barrier at all:
 //   * the tile's depth-sorted id list is walked in rounds of 64: lane i gathers the 48-byte
 //     record of splat (base + i) with three 16-byte loads (the next round is prefetched while
-//     the current one is composited);
-//   * splat j of the round is broadcast to the wave with v_readlane (SGPR operands feed the
-//     VALU directly);
+//     the current one is composited) and parks it in a wave-private 3 KB LDS slice;
+//   * splat j of the round is read back by all lanes with wave-uniform (broadcast) ds_read_b128:
+//     the LDS pipe issues beside the VALU (11 v_readlane per splat cost 17 % of the kernel time);
 //   * backward: the 4 pixels of a lane are summed in registers, one DPP wave reduction
 //     (row_shr + row_bcast) per value yields the tile total in lane 63, which issues the
 //     global float atomics (one per splat, tile and value).
@@ -78,6 +78,20 @@ __device__ __forceinline__ Rec3 gather_round(const float4* __restrict__ rec, con
     return o;
 }
 
+// The 64 records of a round are parked in a wave-private LDS slice and every splat is read back with
+// wave-uniform (broadcast) ds_read_b128: the LDS pipe issues beside the VALU, where 11 v_readlane per splat
+// would take VALU issue slots.  One wave per workgroup: no barrier, only the compiler fence.
+struct RoundLds {
+    float4* rec;          // [64][3]
+    uint32_t* w;          // [64]
+    __device__ __forceinline__ void put(const Rec3& r, int lane) {
+        __builtin_amdgcn_wave_barrier();
+        rec[lane * 3 + 0] = r.a; rec[lane * 3 + 1] = r.b; rec[lane * 3 + 2] = r.c;
+        w[lane] = r.w;
+        __builtin_amdgcn_wave_barrier();
+    }
+};
+
 }  // namespace
 
 namespace {
@@ -113,6 +127,9 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
         last[q] = 0;
     }
 
+    __shared__ float4 s_rec[64 * 3];
+    __shared__ uint32_t s_w[64];
+    RoundLds lds{s_rec, s_w};
     if (L > 0) {
         Rec3 nxt = gather_round(rec, ids, 0, L, lane);
         auto all_done = [&]() {
@@ -129,14 +146,13 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
             // id words of this round with the quadrant mask narrowed to the quadrants that actually blended
             // the splat (0 for splats not reached): the backward skips everything else without testing
             uint32_t neww = cur.w & GGS_ID_MASK;
+            lds.put(cur, lane);
             for (int j = 0; j < n; ++j) {
-                const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, j);
+                const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[j]);
                 uint32_t blended = 0;
-                const float gx = bcast(cur.a.x, j), gy = bcast(cur.a.y, j);
-                const float cxx = bcast(cur.a.z, j), cxy = bcast(cur.a.w, j), cyy = bcast(cur.b.x, j);
-                const float op = bcast(cur.b.y, j);
-                const float cr = bcast(cur.b.z, j), cg = bcast(cur.b.w, j), cb = bcast(cur.c.x, j);
-                const float dep = bcast(cur.c.y, j);
+                const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1], rc = s_rec[j * 3 + 2];
+                const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y;
+                const float cr = rb.z, cg = rb.w, cb = rc.x, dep = rc.y;
                 const uint32_t pos = (uint32_t)(first + j + 1);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
@@ -260,6 +276,9 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
     for (int d = 32; d > 0; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
     if (maxc == 0) return;
 
+    __shared__ float4 s_rec[64 * 3];
+    __shared__ uint32_t s_w[64];
+    RoundLds lds{s_rec, s_w};
     // rounds of 64 list positions, walked from the back: round r covers [64 r, 64 r + 64)
     int r = (maxc - 1) >> 6;
     Rec3 nxt = gather_round(rec, ids, r * 64, L, lane);
@@ -268,15 +287,14 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
         if (r > 0) nxt = gather_round(rec, ids, (r - 1) * 64, L, lane);
         const int first = r * 64;
         const int n = min(64, maxc - first);
+        lds.put(cur, lane);
         for (int j = n - 1; j >= 0; --j) {
             const int pos = first + j;                  // list position; pixel q blended it iff pos < nc[q]
-            const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, j);
+            const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[j]);
             if (!(word & my_bits)) continue;            // the forward blended this splat nowhere in this wave's pixels
-            const float gx = bcast(cur.a.x, j), gy = bcast(cur.a.y, j);
-            const float cxx = bcast(cur.a.z, j), cxy = bcast(cur.a.w, j), cyy = bcast(cur.b.x, j);
-            const float op = bcast(cur.b.y, j);
-            const float cr = bcast(cur.b.z, j), cg = bcast(cur.b.w, j), cb = bcast(cur.c.x, j);
-            const float dep = bcast(cur.c.y, j);
+            const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1], rc = s_rec[j * 3 + 2];
+            const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y;
+            const float cr = rb.z, cg = rb.w, cb = rc.x, dep = rc.y;
             float v_mx = 0.f, v_my = 0.f, v_cx = 0.f, v_cy = 0.f, v_cz = 0.f, v_op = 0.f;
             float v_r = 0.f, v_g = 0.f, v_b = 0.f, v_dep = 0.f;
 #pragma unroll
