@@ -57,10 +57,11 @@ struct SplatAux {
 };
 static_assert(sizeof(SplatAux) == 8, "SplatAux must be 8 bytes");
 
-struct GradRec {                 // per-(view, Gaussian) gradient accumulators
-    float mx, my;                // d/d(pixel mean)
-    float cx, cy, cz;            // d/d(conic)   (cy = true off-diagonal derivative)
-    float opacity;
+struct GradRec {                 // per-(view, Gaussian) accumulators over the pixels that blended the splat,
+                                 // with t = G dL/dalpha and d = mean - pixel:
+    float mx, my;                // sum t dx, sum t dy          (-> d/d pixel mean = -opacity (conic . sums))
+    float cx, cy, cz;            // sum t dx^2, sum t dx dy, sum t dy^2   (-> d/d conic = -opacity (1/2, 1, 1/2) .)
+    float opacity;               // sum t                       (= d/d opacity)
     float r, g, b;
     float depth;
     float pad0, pad1;

@@ -379,7 +379,13 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a) {
         const float cc = (e.M[3] * s1[0] + e.M[4] * s1[1] + e.M[5] * s1[2]) + GGS_LOWPASS;
         const float det = ca * cc - cb * cb;
         const float d2i = 1.f / (det * det + GGS_DET_EPS);
-        const float q0 = g0.z, q1 = g0.w, q2 = g1.x;
+        // raw pixel moments -> gradients w.r.t. the conic and the pixel mean (constants applied once here)
+        const float4* rp = reinterpret_cast<const float4*>(a.rec + vg);
+        const float4 r0 = rp[0], r1 = rp[1];                  // px py cx cy | cz opacity r g
+        const float opac = r1.y;
+        const float q0 = -0.5f * opac * g0.z, q1 = -opac * g0.w, q2 = -0.5f * opac * g1.x;
+        const float g_mx = -opac * (r0.z * g0.x + r0.w * g0.y);
+        const float g_my = -opac * (r1.x * g0.y + r0.w * g0.x);
         const float da = d2i * (-cc * cc * q0 + cb * cc * q1 - cb * cb * q2);
         const float dc = d2i * (-cb * cb * q0 + ca * cb * q1 - ca * ca * q2);
         const float db = d2i * (2.f * cb * cc * q0 - (det + 2.f * cb * cb) * q1 + 2.f * ca * cb * q2);
@@ -409,7 +415,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a) {
         dmean[2] += view[8] * dtx + view[9] * dty + view[10] * dtz;
 
         // pixel mean -> NDC -> mean3D
-        const float gnx = g0.x * 0.5f * (float)a.W, gny = g0.y * 0.5f * (float)a.H;
+        const float gnx = g_mx * 0.5f * (float)a.W, gny = g_my * 0.5f * (float)a.H;
         if (o2) { o2[0] = gnx; o2[1] = gny; o2[2] = 0.f; }
         const float hx = proj[0] * m[0] + proj[4] * m[1] + proj[8] * m[2] + proj[12];
         const float hy = proj[1] * m[0] + proj[5] * m[1] + proj[9] * m[2] + proj[13];

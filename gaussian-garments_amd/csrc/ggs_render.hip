@@ -318,14 +318,17 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
                 B[q] = fmaf(w, sdot, B[q]);
                 v_r = fmaf(w, dC0[q], v_r); v_g = fmaf(w, dC1[q], v_g); v_b = fmaf(w, dC2[q], v_b);
                 if (DA) v_dep = fmaf(w, dD[q], v_dep);
-                const float dL_dG = op * dL_da;            // straight through the 0.99 clamp
-                const float gdx = G * dx, gdy = G * dy;
-                v_mx = fmaf(dL_dG, -gdx * cxx - gdy * cxy, v_mx);
-                v_my = fmaf(dL_dG, -gdy * cyy - gdx * cxy, v_my);
-                v_cx = fmaf(-0.5f * gdx * dx, dL_dG, v_cx);
-                v_cy = fmaf(-gdx * dy, dL_dG, v_cy);
-                v_cz = fmaf(-0.5f * gdy * dy, dL_dG, v_cz);
-                v_op = fmaf(G, dL_da, v_op);
+                // Geometry terms are accumulated as RAW moments of h = G dL/dG over the pixels
+                //   (sum h, sum h dx, sum h dy, sum h dx^2, sum h dx dy, sum h dy^2);
+                // the per-splat constants (conic, opacity, -1/2) are applied once per Gaussian in the
+                // per-Gaussian backward instead of once per pixel here (straight through the 0.99 clamp).
+                const float t = G * dL_da;
+                v_op += t;                                   // = sum G dL/dalpha  (d/d opacity)
+                const float hx = t * dx, hy = t * dy;        // the common factor `opacity` is applied later
+                v_mx += hx; v_my += hy;
+                v_cx = fmaf(hx, dx, v_cx);
+                v_cy = fmaf(hx, dy, v_cy);
+                v_cz = fmaf(hy, dy, v_cz);
             }
             // totals land in: S1 lanes 15/31/47/63 = (mx, cx, my, cy); S2 = (cz, r, op, g); S3 lanes 31/63 = (b, depth)
             const float S1 = row_sum_lane15(swap16_add(swap32_add(v_mx, v_my), swap32_add(v_cx, v_cy)));
