@@ -42,9 +42,16 @@
 #define GGS_T_MIN 0.0001f
 #define GGS_DET_EPS 0.0000001f
 
+// The conic is stored PRE-SCALED for the compositing loops: with d = mean - pixel,
+//   log2(G) = qa dx^2 + qb dx dy + qc dy^2,   qa = -log2(e)/2 conic.x, qb = -log2(e) conic.y, qc = -log2(e)/2 conic.z
+// so the exponent costs 3 mul + 2 fma + one v_exp_f32 per pixel instead of 9 VALU ops + mul + v_exp.
+#define GGS_KA (-0.72134752044448170f)   // -log2(e) / 2
+#define GGS_KB (-1.44269504088896340f)   // -log2(e)
+#define GGS_LOG2E 1.44269504088896340f
+
 struct SplatRec {                // float index
-    float px, py, cx, cy;        // 0..3   pixel mean, conic.x, conic.y
-    float cz, opacity, r, g;     // 4..7   conic.z, opacity, colour r, g
+    float px, py, cx, cy;        // 0..3   pixel mean, qa, qb  (pre-scaled conic, see above)
+    float cz, opacity, r, g;     // 4..7   qc, opacity, colour r, g
     float b, depth;              // 8..9   colour b, view-space depth
     unsigned bbx, bby;           // 10..11 pixel AABB of the region where alpha can reach 1/255:
                                  //        int16 min | int16 max << 16 (conservative; empty if min > max)
@@ -168,12 +175,14 @@ __device__ __forceinline__ void ggs_cull_rect(unsigned bbx, unsigned bby, int& x
 // clamped 1-D parabola.  The box is continuous, so this is a superset of what any pixel centre can pass.
 struct Footprint { float mx, my, A, B, C, lim, BoC, BoA; };   // lim = 2 tau (<= 0: never blended); B/C, B/A
 
-__device__ __forceinline__ Footprint ggs_footprint(float px, float py, float cx, float cy, float cz, float opacity) {
+// From the STORED record fields (qa, qb, qc pre-scaled): the quadratic form is scaled by log2(e)/2, and so is
+// the limit.  Histogram and scatter both build it from the record, so they agree bit for bit.
+__device__ __forceinline__ Footprint ggs_footprint(float px, float py, float qa, float qb, float qc, float opacity) {
     Footprint f;
-    f.mx = px; f.my = py; f.A = cx; f.B = cy; f.C = cz;
+    f.mx = px; f.my = py; f.A = -qa; f.B = -0.5f * qb; f.C = -qc;
     const float tau = (opacity > 0.f ? logf(255.f * opacity) : -1.f) * 1.01f + 0.02f;
-    f.lim = 2.f * tau;
-    f.BoC = cy / cz; f.BoA = cy / cx;
+    f.lim = tau * GGS_LOG2E;
+    f.BoC = f.B / f.C; f.BoA = f.B / f.A;
     return f;
 }
 

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
             if ((x1 - x0) * (y1 - y0) != 0) {
                 radius = (int)rad;
                 out.px = px; out.py = py;
-                out.cx = cc * det_inv; out.cy = -cb * det_inv; out.cz = ca * det_inv;
+                out.cx = GGS_KA * (cc * det_inv); out.cy = GGS_KB * (-cb * det_inv); out.cz = GGS_KA * (ca * det_inv);
                 out.opacity = a.opacities[g];
                 out.depth = pvz;
                 ggs_alpha_bbox(px, py, ca, cc, out.opacity, out.bbx, out.bby);
@@ -380,12 +380,12 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a) {
         const float det = ca * cc - cb * cb;
         const float d2i = 1.f / (det * det + GGS_DET_EPS);
         // raw pixel moments -> gradients w.r.t. the conic and the pixel mean (constants applied once here)
-        const float4* rp = reinterpret_cast<const float4*>(a.rec + vg);
-        const float4 r0 = rp[0], r1 = rp[1];                  // px py cx cy | cz opacity r g
-        const float opac = r1.y;
+        const float opac = reinterpret_cast<const float4*>(a.rec + vg)[1].y;   // SplatRec.opacity
+        const float det_inv = 1.f / det;
+        const float kx = cc * det_inv, ky = -cb * det_inv, kz = ca * det_inv;     // the conic
         const float q0 = -0.5f * opac * g0.z, q1 = -opac * g0.w, q2 = -0.5f * opac * g1.x;
-        const float g_mx = -opac * (r0.z * g0.x + r0.w * g0.y);
-        const float g_my = -opac * (r1.x * g0.y + r0.w * g0.x);
+        const float g_mx = -opac * (kx * g0.x + ky * g0.y);
+        const float g_my = -opac * (kz * g0.y + ky * g0.x);
         const float da = d2i * (-cc * cc * q0 + cb * cc * q1 - cb * cb * q2);
         const float dc = d2i * (-cb * cb * q0 + ca * cb * q1 - ca * ca * q2);
         const float db = d2i * (2.f * cb * cc * q0 - (det + 2.f * cb * cb) * q1 + 2.f * ca * cb * q2);

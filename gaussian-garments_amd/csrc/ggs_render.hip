@@ -159,8 +159,8 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
                     if (!(word & (1u << (GGS_ID_BITS + q0 + q)))) continue;   // wave-uniform: one scalar branch
                     // predicated, branch-free per-pixel update: lane masks instead of nested exec juggling
                     const float dx = gx - pxf[q], dy = gy - pyf[q];
-                    const float power = -0.5f * (cxx * dx * dx + cyy * dy * dy) - cxy * dx * dy;
-                    const float alpha = ggs_min(GGS_ALPHA_MAX, op * __expf(power));
+                    const float power = fmaf(cxx * dx, dx, fmaf(cyy * dy, dy, (cxy * dx) * dy));   // log2 of the falloff
+                    const float alpha = ggs_min(GGS_ALPHA_MAX, op * __builtin_amdgcn_exp2f(power));
                     const bool ok = !done[q] & (power <= 0.f) & (alpha >= GGS_ALPHA_MIN);
                     if (!__any(ok)) continue;
                     const float test_T = T[q] * (1.f - alpha);
@@ -301,8 +301,8 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
             for (int q = 0; q < NQ; ++q) {
                 if (!(word & (1u << (GGS_ID_BITS + q0 + q)))) continue;   // quadrant did not blend it (forward's mask)
                 const float dx = gx - pxf[q], dy = gy - pyf[q];
-                const float power = -0.5f * (cxx * dx * dx + cyy * dy * dy) - cxy * dx * dy;
-                const float Gr = __expf(power);
+                const float power = fmaf(cxx * dx, dx, fmaf(cyy * dy, dy, (cxy * dx) * dy));       // log2 of the falloff
+                const float Gr = __builtin_amdgcn_exp2f(power);
                 const float ar = ggs_min(GGS_ALPHA_MAX, op * Gr);
                 const bool valid = (pos < nc[q]) & (power <= 0.f) & (ar >= GGS_ALPHA_MIN);
                 // predication instead of branches: a lane that did not blend this splat carries

@@ -169,7 +169,10 @@ def test_internals_bit_exact():
     vis = co.radii > 0
     assert np.array_equal(rec[vis, 0:2], it["xy"][vis])
     assert np.array_equal(rec[vis, 9], it["depth"][vis])
-    assert np.array_equal(rec[vis][:, [2, 3, 4, 5]], it["conic_opacity"][vis])
+    # the record stores the conic pre-scaled for the compositing loops: (-log2e/2, -log2e, -log2e/2) * conic
+    k = np.array([-0.72134752044448170, -1.44269504088896340, -0.72134752044448170], dtype=np.float32)
+    assert np.array_equal(rec[vis][:, [2, 3, 4]], (it["conic_opacity"][vis][:, :3] * k[None, :]).astype(np.float32))
+    assert np.array_equal(rec[vis][:, 5], it["conic_opacity"][vis][:, 3])
     assert np.array_equal(rec[vis][:, [6, 7, 8]], it["rgb"][vis])
 
 
