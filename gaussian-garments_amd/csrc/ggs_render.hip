@@ -116,13 +116,14 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
 
     float pxf[NQ], pyf[NQ], T[NQ], C0[NQ], C1[NQ], C2[NQ], D[NQ], A[NQ];
     uint32_t last[NQ];
-    bool done[NQ], inside[NQ];
+    bool inside[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         const int px = px0 + ((q0 + q) & 1) * 8, py = py0 + ((q0 + q) >> 1) * 8;
         inside[q] = px < a.W && py < a.H;
-        done[q] = !inside[q];
-        pxf[q] = (float)px; pyf[q] = (float)py;
+        // a finished pixel parks its x coordinate at +inf: the falloff exponent becomes -inf or NaN and
+        // every later splat fails the (power <= 0, alpha >= 1/255) test without a separate flag
+        pxf[q] = inside[q] ? (float)px : __builtin_inff(); pyf[q] = (float)py;
         T[q] = 1.f; C0[q] = C1[q] = C2[q] = D[q] = A[q] = 0.f;
         last[q] = 0;
     }
@@ -135,8 +136,8 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
         auto all_done = [&]() {
             bool d = true;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) d = d && done[q];
-            return __all(d);
+            for (int q = 0; q < NQ; ++q) d = d && (pxf[q] == __builtin_inff());
+            return __builtin_amdgcn_ballot_w64(!d) == 0;
         };
         for (int first = 0; first < L; first += 64) {
             if (all_done()) break;
@@ -153,29 +154,31 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
                 const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1], rc = s_rec[j * 3 + 2];
                 const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y;
                 const float cr = rb.z, cg = rb.w, cb = rc.x, dep = rc.y;
-                const uint32_t pos = (uint32_t)(first + j + 1);
+                uint32_t posv;   // list position + 1, materialised in a VGPR once per splat (not once per quadrant)
+                asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + j + 1));
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     if (!(word & (1u << (GGS_ID_BITS + q0 + q)))) continue;   // wave-uniform: one scalar branch
                     // predicated, branch-free per-pixel update: lane masks instead of nested exec juggling
                     const float dx = gx - pxf[q], dy = gy - pyf[q];
                     const float power = fmaf(cxx * dx, dx, fmaf(cyy * dy, dy, (cxy * dx) * dy));   // log2 of the falloff
-                    const float alpha = ggs_min(GGS_ALPHA_MAX, op * __builtin_amdgcn_exp2f(power));
-                    const bool ok = !done[q] & (power <= 0.f) & (alpha >= GGS_ALPHA_MIN);
-                    if (!__any(ok)) continue;
-                    const float test_T = T[q] * (1.f - alpha);
+                    const float alpha = __builtin_fminf(GGS_ALPHA_MAX, op * __builtin_amdgcn_exp2f(power));
+                    const bool ok = (power <= 0.f) & (alpha >= GGS_ALPHA_MIN);
+                    if (__builtin_amdgcn_ballot_w64(ok) == 0) continue;
+                    const float wa = alpha * T[q];
+                    const float test_T = T[q] - wa;           // = T (1 - alpha)
                     const bool stop = ok & (test_T < GGS_T_MIN);
                     const bool app = ok & !stop;
-                    done[q] |= stop;
-                    const float w = app ? alpha * T[q] : 0.f;
+                    pxf[q] = stop ? __builtin_inff() : pxf[q];
+                    const float w = app ? wa : 0.f;
                     C0[q] = fmaf(cr, w, C0[q]);
                     C1[q] = fmaf(cg, w, C1[q]);
                     C2[q] = fmaf(cb, w, C2[q]);
                     D[q] = fmaf(dep, w, D[q]);
                     A[q] += w;
-                    T[q] = app ? test_T : T[q];
-                    last[q] = app ? pos : last[q];
-                    if (__any(app)) blended |= 1u << (GGS_ID_BITS + q0 + q);
+                    T[q] -= w;
+                    last[q] = app ? posv : last[q];
+                    if (__builtin_amdgcn_ballot_w64(w > 0.f) != 0) blended |= 1u << (GGS_ID_BITS + q0 + q);   // w > 0 <=> app
                 }
                 if (NQ == 4) {
                     if (lane == j) neww |= blended;
@@ -303,7 +306,7 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
                 const float dx = gx - pxf[q], dy = gy - pyf[q];
                 const float power = fmaf(cxx * dx, dx, fmaf(cyy * dy, dy, (cxy * dx) * dy));       // log2 of the falloff
                 const float Gr = __builtin_amdgcn_exp2f(power);
-                const float ar = ggs_min(GGS_ALPHA_MAX, op * Gr);
+                const float ar = __builtin_fminf(GGS_ALPHA_MAX, op * Gr);
                 const bool valid = (pos < nc[q]) & (power <= 0.f) & (ar >= GGS_ALPHA_MIN);
                 // predication instead of branches: a lane that did not blend this splat carries
                 // alpha = G = 0, which zeroes every contribution and leaves (T, B) unchanged.
