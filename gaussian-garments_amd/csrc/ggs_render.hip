@@ -11,9 +11,9 @@
 //     the current one is composited) and parks it in a wave-private 3 KB LDS slice;
 //   * splat j of the round is read back by all lanes with wave-uniform (broadcast) ds_read_b128:
 //     the LDS pipe issues beside the VALU (11 v_readlane per splat cost 17 % of the kernel time);
-//   * backward: the 4 pixels of a lane are summed in registers, one DPP wave reduction
-//     (row_shr + row_bcast) per value yields the tile total in lane 63, which issues the
-//     global float atomics (one per splat, tile and value).
+//   * backward: the 4 pixels of a lane are summed in registers, a permlane-swap / masked-DPP butterfly
+//     folds the 9-10 values into ONE register (each total in its own lane), and a single vector
+//     float-atomic instruction adds them to the splat's GradRec.
 //
 // Roofline: HBM nominally (algorithmic bytes: forward N*48 B gathers + 28 B/pixel outputs;
 // backward N*48 + 20 B/pixel + N*36 B of atomics), VALU/exp bound in practice:
@@ -30,10 +30,10 @@ __device__ __forceinline__ float dpp_fetch(float v) {
 // ---- wave reduction of the 10 per-splat gradient values ----------------------------------------
 // gfx950 has v_permlane32_swap / v_permlane16_swap: exchanging halves (rows) between TWO registers
 // and adding folds two values at once, so the 64-lane sums of 10 values cost 28 VALU ops instead of
-// 10 x 8 with one DPP chain per value:
+// 10 x 8 with one DPP chain per value (21 ops without depth/alpha gradients):
 //   swap32_add(x, y)   -> lanes 0-31: 32 partials of x        | lanes 32-63: 32 partials of y
 //   swap16_add(z1, z2) -> rows 0..3 (16 lanes each): partials of (z1.lo, z2.lo, z1.hi, z2.hi)
-//   row_sum_lane15     -> lane 15 of every row = that row's total (4 DPP row_shr adds)
+//   fold_rows          -> the three row-partial registers folded into one, each total in one lane
 __device__ __forceinline__ float swap32_add(float x, float y) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
@@ -42,18 +42,39 @@ __device__ __forceinline__ float swap16_add(float z1, float z2) {
     const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(z1), __float_as_uint(z2), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ __forceinline__ float row_sum_lane15(float v) {
-    v += dpp_fetch<0x111, 0xf>(v);   // row_shr:1
-    v += dpp_fetch<0x112, 0xf>(v);   // row_shr:2
-    v += dpp_fetch<0x114, 0xf>(v);   // row_shr:4
-    v += dpp_fetch<0x118, 0xf>(v);   // row_shr:8  -> lane 15 of each row = row total
-    return v;
-}
-// two values in the two 32-lane halves -> totals in lanes 31 and 63
-__device__ __forceinline__ float half_sum_lane31_63(float v) {
-    v = row_sum_lane15(v);
-    v += dpp_fetch<0x142, 0xa>(v);   // row_bcast:15 into rows 1 and 3
-    return v;
+// Rows -> quads.  q1 and q2 hold one value per 16-lane row, r5 one value per row (or per pair of rows); DPP adds
+// with a bank mask write only part of a row, so two registers fold into one per step instead of each being
+// reduced on its own:
+//   row_ror:8  : lanes 0-7 of a row <- q1 pair sums, lanes 8-15 <- q2 pair sums;  r5 += ror8(r5)
+//   row_ror:4/12: lanes 0-3 / 8-11 <- q1 / q2 sums of 4,  lanes 4-7 / 12-15 <- r5 sums of 4
+//   quad_perm  : two more adds leave every quad with its total.
+// Result, per row: quad 0 = q1's row total, quad 2 = q2's row total; r5's totals: see the end of the function.
+// (s_nop: 2 wait states between a VALU write and a DPP read of the same VGPR; the assembler does not add them.)
+template <int R5_ROWS>
+__device__ __forceinline__ float fold_rows(float q1, float q2, float r5) {
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 0\n\t"
+        "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xa"
+        : "+v"(q1), "+v"(r5) : "v"(q2));
+    q1 += dpp_fetch<0x4E, 0xf>(q1);   // quad_perm:[2,3,0,1]
+    q1 += dpp_fetch<0xB1, 0xf>(q1);   // quad_perm:[1,0,3,2]
+    // r5's row totals (quads 1 and 3) are folded across rows so that every value ends in exactly ONE lane: several
+    // lanes of one atomic instruction hitting the same address serialise in the L2 (measured: +50 % kernel time).
+    if (R5_ROWS == 2) {      // r5 = (b, b, depth, depth) by rows -> quad 1 of row 1 = b, of row 3 = depth
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0x2" : "+v"(q1));
+    } else {                 // r5 = b in all four rows -> quad 1 of row 3 = b
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xa\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0x8 bank_mask:0x2" : "+v"(q1));
+    }
+    return q1;
 }
 
 __device__ __forceinline__ float bcast(float v, int lane) {
@@ -270,10 +291,13 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
         }
         B[q] = T[q] * (bg0 * dC0[q] + bg1 * dC1[q] + bg2 * dC2[q]);
     }
-    // GradRec field written by this lane after the reduction: row r of 16 lanes ends up with field
-    // pair-index ((r & 1) << 1) | (r >> 1) of {mx,my,cx,cy} (and of {cz,op,r,g} at +4)
-    const int row = lane >> 4;
-    const int fld = ((row & 1) << 1) | (row >> 1);
+    // GradRec field this lane adds to after the reduction (fold_rows): first lane of quad 0 / 2 / 1 of each row
+    const int row = lane >> 4, quad = (lane >> 2) & 3;
+    int fld = -1;
+    if ((lane & 3) == 0 && quad != 3) {
+        const int pr = ((row & 1) << 1) | (row >> 1);       // rows hold fields 0, 2, 1, 3 of a 4-group
+        fld = quad == 0 ? pr : quad == 2 ? 4 + pr : row == 3 ? (DA ? 9 : 8) : (DA && row == 1) ? 8 : -1;
+    }
     // wave max of the per-pixel contributor counts
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
@@ -333,17 +357,13 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
                 v_cy = fmaf(hx, dy, v_cy);
                 v_cz = fmaf(hy, dy, v_cz);
             }
-            // totals land in: S1 lanes 15/31/47/63 = (mx, cx, my, cy); S2 = (cz, r, op, g); S3 lanes 31/63 = (b, depth)
-            const float S1 = row_sum_lane15(swap16_add(swap32_add(v_mx, v_my), swap32_add(v_cx, v_cy)));
-            const float S2 = row_sum_lane15(swap16_add(swap32_add(v_cz, v_op), swap32_add(v_r, v_g)));
-            const float S3 = half_sum_lane31_63(swap32_add(v_b, v_dep));
+            // rows of Q1 = (mx, cx, my, cy), of Q2 = (cz, r, op, g); R5 = b in every row (DA: b, b, depth, depth)
+            const float Q1 = swap16_add(swap32_add(v_mx, v_my), swap32_add(v_cx, v_cy));
+            const float Q2 = swap16_add(swap32_add(v_cz, v_op), swap32_add(v_r, v_g));
+            const float S = DA ? fold_rows<2>(Q1, Q2, swap32_add(v_b, v_dep)) : fold_rows<4>(Q1, Q2, v_b);
             const uint32_t gid = word & GGS_ID_MASK;
             float* dst = reinterpret_cast<float*>(acc + gid);
-            if ((lane & 15) == 15) {                         // 4 lanes issue 4 atomics per instruction
-                atomicAdd(dst + fld, S1);
-                atomicAdd(dst + 4 + fld, S2);
-                if ((row & 1) && (DA || row == 1)) atomicAdd(dst + 8 + (row >> 1), S3);
-            }
+            if (fld >= 0) atomicAdd(dst + fld, S);           // one instruction, 9 (10) lanes, all addresses distinct
         }
     }
 }
