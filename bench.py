@@ -200,7 +200,7 @@ def main():
                                    "frac": round(B_view * views_per_sec / 1e9 / HBM_PEAK_GBS, 5)}}
 
         # ---- per-view drop-in loop (render() + autograd, one camera per call like the reference) ----
-        loop_vps = step_vps = None
+        loop_vps = step_vps = graph_vps = None
         if args.loop_views > 0:
             from ggsplat.render import render
             from types import SimpleNamespace
@@ -239,6 +239,23 @@ def main():
             steps()
             torch.cuda.synchronize(dev)
             step_vps = len(lcams) / (time.perf_counter() - t1)
+
+            # the same step captured once into a hipGraph and replayed per iteration (GraphedRegistrationStep:
+            # guarded GraphAdam, static camera / image buffers, one host sync per iteration)
+            from ggsplat.adam import GraphAdam
+            from ggsplat.inner_step import GraphedRegistrationStep
+            model.optimizer = GraphAdam(model.optimizer.param_groups, lr=0.0, eps=1e-15)
+            gstep = GraphedRegistrationStep(model, W, H, bg)
+            for c in lcams[:2]:
+                gstep(c, gt_img, gt_mask)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for c in lcams:
+                gstep(c, gt_img, gt_mask)
+            torch.cuda.synchronize(dev)
+            graph_vps = len(lcams) / (time.perf_counter() - t1)
+            graph_recaptures = gstep.recaptures
+            del gstep
             model.optimizer = None
 
         # ---- CPU baseline: the C oracle on the host cores, bounded sample of the same views ----
@@ -277,6 +294,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
             "per_view_loop_views_per_sec": None if loop_vps is None else round(loop_vps, 2),
             "s2_inner_step_iters_per_sec": None if step_vps is None else round(step_vps, 2),
+            "s2_graph_step_iters_per_sec": None if graph_vps is None else round(graph_vps, 2),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

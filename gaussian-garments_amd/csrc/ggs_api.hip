@@ -164,6 +164,30 @@ size_t ggs_backward_scratch_bytes(const GgsParams* p) {
 }  // extern "C"
 
 namespace {
+__global__ __launch_bounds__(256) void k_zero(uint32_t* p, size_t n_words, size_t head, size_t n_vec) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    uint4* v = reinterpret_cast<uint4*>(p + head);
+    for (size_t k = i; k < n_vec; k += stride) v[k] = make_uint4(0, 0, 0, 0);
+    if (i < head) p[i] = 0;                                             // words in front of the 16-byte boundary
+    const size_t tail0 = head + n_vec * 4;
+    if (i < n_words - tail0) p[tail0 + i] = 0;                          // < 4 words behind the vector part
+}
+}  // namespace
+
+hipError_t ggs_zero_async(void* ptr, size_t bytes, hipStream_t s) {
+    if (bytes == 0) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(ptr) & 3) || (bytes & 3)) return hipErrorInvalidValue;
+    const size_t n_words = bytes / 4;
+    size_t head = ((16 - (reinterpret_cast<uintptr_t>(ptr) & 15)) & 15) / 4;
+    if (head > n_words) head = n_words;
+    const size_t n_vec = (n_words - head) / 4;
+    size_t blocks = (n_vec + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+    hipLaunchKernelGGL(k_zero, dim3((unsigned)blocks), dim3(256), 0, s, static_cast<uint32_t*>(ptr), n_words, head, n_vec);
+    return hipGetLastError();
+}
+
+namespace {
 enum { PHASE_COUNT = 1, PHASE_RENDER = 2 };
 
 // PHASE_COUNT : clear counters, preprocess (+ tile histogram), scan, work-item order  -> header.num_rendered
@@ -201,8 +225,8 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
 
     const dim3 gridP((unsigned)((p->P + 255) / 256), (unsigned)V);
     if (phases & PHASE_COUNT) {
-    if (hipMemsetAsync(bin, 0, L.zero_bytes, s) != hipSuccess)
-        return fail(GGS_ERR_HIP, "ggs_forward: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
+    if (ggs_zero_async(bin, L.zero_bytes, s) != hipSuccess)
+        return fail(GGS_ERR_HIP, "ggs_forward: clearing the binning counters failed: %s", hipGetErrorString(hipGetLastError()));
     if (p->P > 0) {
         PreArgs a;
         a.P = p->P; a.K = p->K; a.deg = p->sh_degree; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T;
@@ -316,8 +340,8 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
     const char* b = (const char*)bin;
     const size_t HW = (size_t)p->W * p->H;
 
-    if (hipMemsetAsync(scratch, 0, (size_t)V * p->P * sizeof(GradRec), s) != hipSuccess)
-        return fail(GGS_ERR_HIP, "ggs_backward: hipMemsetAsync failed: %s", hipGetErrorString(hipGetLastError()));
+    if (ggs_zero_async(scratch, (size_t)V * p->P * sizeof(GradRec), s) != hipSuccess)
+        return fail(GGS_ERR_HIP, "ggs_backward: clearing the gradient records failed: %s", hipGetErrorString(hipGetLastError()));
     {
         RenderBwdArgs a;
         a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T;
@@ -331,6 +355,7 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
         a.n_contrib = (const uint32_t*)((const char*)img + ggs_align((size_t)V * HW * 4));
         a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth; a.dL_dalpha = dL_dalpha;
         a.acc = (GradRec*)scratch;
+        a.header = (const GgsBinHeader*)(b + L.header);
         const dim3 gridT((unsigned)(V * d.T));   // one wave64 per (view, tile) work item, longest lists first
         prof_start(K_RENDER_BWD, s);
         const bool da = dL_ddepth || dL_dalpha;

@@ -86,6 +86,7 @@ struct RenderBwdArgs {
     const float* dL_ddepth;   // [V][H][W] or null
     const float* dL_dalpha;   // [V][H][W] or null
     GradRec* acc;             // [V][P]
+    const GgsBinHeader* header;   // overflow != 0: the forward did not composite -> the backward does nothing
 };
 
 struct PreBwdArgs {
@@ -121,3 +122,9 @@ __global__ void ggs_k_reduce_partials(PreBwdArgs a, int splits);
 // host-side error plumbing (ggs_api.hip)
 int ggs_fail_(int code, const char* fmt, ...);
 void ggs_clear_error_();
+
+// Zero-fill as a KERNEL, not hipMemsetAsync: memset nodes of a captured hipGraph were observed not to re-execute
+// faithfully on replay (counters kept their values from the previous replay -> list overflow, memory fault), and
+// every entry point must behave identically whether it is launched eagerly or replayed from a graph.
+// p must be 4-byte aligned, bytes a multiple of 4.  Returns hipSuccess / the launch error.
+hipError_t ggs_zero_async(void* p, size_t bytes, hipStream_t s);

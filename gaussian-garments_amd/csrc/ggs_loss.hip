@@ -213,8 +213,8 @@ int ggs_photometric_forward(int n_views, int H, int W, const float* img, const f
     if (!sums) return ggs_fail_(GGS_ERR_ARG, "ggs_photometric_forward: sums is NULL");
     hipStream_t s = (hipStream_t)stream_;
     a.sums = sums;
-    if (hipMemsetAsync(sums, 0, (size_t)n_views * 2 * sizeof(float), s) != hipSuccess)
-        return ggs_fail_(GGS_ERR_HIP, "ggs_photometric_forward: hipMemsetAsync failed");
+    if (ggs_zero_async(sums, (size_t)n_views * 2 * sizeof(float), s) != hipSuccess)
+        return ggs_fail_(GGS_ERR_HIP, "ggs_photometric_forward: clearing the sums failed");
     const dim3 grid((unsigned)((W + LT - 1) / LT), (unsigned)((H + LT - 1) / LT), (unsigned)(n_views * 3));
     hipLaunchKernelGGL(ggs_k_loss_stats, grid, dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();

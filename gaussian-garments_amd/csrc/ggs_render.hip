@@ -243,6 +243,7 @@ namespace {
 // K5 body.  DA: gradients of the depth / alpha outputs are present.
 template <bool DA, int NQ>
 __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
+    if (a.header->overflow) return;          // lists and per-pixel state were never written (captured-step replay)
     const uint32_t item = a.order[NQ == 4 ? blockIdx.x : blockIdx.x >> 2];   // work items, longest lists first
     const int q0 = NQ == 4 ? 0 : (int)(blockIdx.x & 3);                      // NQ = 1: one wave per quadrant
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;

@@ -261,8 +261,8 @@ int ggs_visibility(int P, int F, int n_verts, const float* verts, const int64_t*
     a.cell_cursor = (unsigned*)(b + L.cursor); a.cell_offset = (unsigned*)(b + L.offset);
     a.global_ids = (unsigned*)(b + L.global_ids); a.tri_ids = (unsigned*)(b + L.tri_ids);
     a.mask = mask; a.first_hit = first_hit;
-    if (hipMemsetAsync(scratch, 0, L.proj, s) != hipSuccess)          // header + count + cursor
-        return ggs_fail_(GGS_ERR_HIP, "ggs_visibility: hipMemsetAsync failed");
+    if (ggs_zero_async(scratch, L.proj, s) != hipSuccess)             // header + count + cursor
+        return ggs_fail_(GGS_ERR_HIP, "ggs_visibility: clearing the grid counters failed");
     const int gv = n_verts > 0 ? (n_verts + 255) / 256 : 1, gf = F > 0 ? (F + 255) / 256 : 1;
     if (n_verts > 0 && F > 0) {
         hipLaunchKernelGGL(k_vis_sum, dim3(gv < 512 ? gv : 512), dim3(256), 0, s, a);

@@ -46,6 +46,9 @@ _SIGS = {
     "ggs_fused_bias_act": (C.c_int, [C.c_size_t, _PTR, _PTR, _PTR, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _PTR, _PTR]),
     "ggs_upfirdn2d_out_size": (C.c_int, [C.c_int] * 12 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ggs_upfirdn2d": (C.c_int, [C.c_int] * 4 + [_PTR, _PTR] + [C.c_int] * 10 + [_PTR, _PTR]),
+    "ggs_adam_state_bytes": (C.c_size_t, []),
+    "ggs_adam_tick": (C.c_int, [_PTR, C.c_double, C.c_double, _PTR, _PTR]),
+    "ggs_adam_step": (C.c_int, [C.c_size_t, _PTR, _PTR, _PTR, _PTR, _PTR, C.c_double, C.c_double, C.c_double, _PTR, _PTR, _PTR]),
     "ggs_visibility_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_size_t]),
     "ggs_visibility": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 6 + [C.c_size_t, _PTR, _PTR, _PTR]),
     "ggs_profile_enable": (C.c_int, [C.c_int]),

@@ -1,0 +1,89 @@
+"""GraphAdam -- the optimiser of the inner loops on the graph-capturable kernels of libggsplat.so.
+
+Stands where the reference builds ``torch.optim.Adam(l, lr=0.0, eps=1e-15)`` (scene/mesh_gaussian_model.py:375,
+gaussian_model.py:165, avatar_net.py:50): same `param_groups` shape ({"params", "lr", "name"}), same update
+(single-tensor Adam without amsgrad / weight decay), `step()` / `zero_grad()`.  Differences, all so that a whole
+optimisation step can be replayed as one hipGraph:
+  * step count, bias corrections and the learning rates live in device memory (`push_lr()` uploads the host-side
+    `param_groups[i]["lr"]` after a schedule update -- a 4-byte-per-group async copy, no re-capture);
+  * moments are allocated up front (nothing is allocated or zero-filled inside a captured step);
+  * `step(guard=...)`: a device int64/uint64 word that voids the whole step when non-zero -- the binning-overflow
+    flag of the forward of the same step (ggsplat.rasterizer.last_header()[1:2]).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Iterable, List, Optional
+
+import torch
+
+from ._lib import check, lib, ptr
+
+
+class GraphAdam:
+    def __init__(self, params: Iterable, lr: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-15):
+        groups = list(params)
+        if groups and not isinstance(groups[0], dict):
+            groups = [{"params": groups}]
+        self.param_groups: List[Dict] = []
+        for g in groups:
+            g = dict(g)
+            g["params"] = list(g["params"])
+            g.setdefault("lr", lr)
+            self.param_groups.append(g)
+        self.betas, self.eps = (float(betas[0]), float(betas[1])), float(eps)
+        first = self.param_groups[0]["params"][0]
+        if first.device.type != "cuda":
+            raise RuntimeError("ggsplat GraphAdam runs on the GPU only (no CPU path in the product)")
+        dev = self.device = first.device
+        L = lib()
+        self._state = torch.zeros(int(L.ggs_adam_state_bytes()), dtype=torch.uint8, device=dev)
+        self._lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
+        self._lr_host = torch.zeros(len(self.param_groups), dtype=torch.float32).pin_memory()
+        self.state: Dict[torch.Tensor, Dict[str, torch.Tensor]] = {}
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.dtype != torch.float32 or not p.is_contiguous():
+                    raise ValueError("GraphAdam: parameters must be contiguous float32 tensors")
+                self.state[p] = {"exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+        self.push_lr()
+
+    # ---- learning rates ---------------------------------------------------------------------------------
+    def push_lr(self) -> None:
+        """Upload param_groups[i]["lr"] to the device (call after changing a learning rate, outside a capture)."""
+        for i, g in enumerate(self.param_groups):
+            self._lr_host[i] = float(g["lr"])
+        self._lr_dev.copy_(self._lr_host, non_blocking=True)
+
+    @property
+    def step_count(self) -> int:
+        return int(self._state[:8].view(torch.int64).item())
+
+    # ---- torch.optim.Optimizer surface ------------------------------------------------------------------
+    def zero_grad(self, set_to_none: bool = True) -> None:
+        for g in self.param_groups:
+            for p in g["params"]:
+                if p.grad is not None:
+                    if set_to_none:
+                        p.grad = None
+                    else:
+                        p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, guard: Optional[torch.Tensor] = None) -> None:
+        L = lib()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if guard is not None and (guard.element_size() != 8 or guard.device != self.device):
+            raise ValueError("GraphAdam.step: guard must be a 64-bit word on the optimiser's device")
+        gp = ptr(guard)
+        b1, b2 = self.betas
+        check(L.ggs_adam_tick(ptr(self._state), b1, b2, gp, stream), "ggs_adam_tick")
+        for i, g in enumerate(self.param_groups):
+            lr = self._lr_dev[i:i + 1]
+            for p in g["params"]:
+                if p.grad is None:
+                    continue
+                grad = p.grad if (p.grad.is_contiguous() and p.grad.dtype == torch.float32) else p.grad.float().contiguous()
+                st = self.state[p]
+                check(L.ggs_adam_step(p.numel(), ptr(p), ptr(grad), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(lr),
+                                      b1, b2, self.eps, ptr(self._state), gp, stream), "ggs_adam_step")

@@ -11,6 +11,8 @@ from typing import Callable, Dict, Optional
 import torch
 import torch.nn.functional as F
 
+from . import rasterizer as R
+from .adam import GraphAdam
 from .loss import fused_photometric_loss, l1_loss, ssim
 from .render import render
 
@@ -42,17 +44,32 @@ def registration_step(gaussians, viewpoint_cam, gt_image, mask, bg, opt=DEFAULT_
     l_img, l_ssim = _photometric(image, gt_image, m, opt.lambda_dssim, fused_loss)
     loss_dict = {"img": l_img, "ssim": l_ssim}
     if first_frame_template:
-        loss_dict["xyz"] = F.relu(gaussians._xyz[vis].norm(dim=1) - opt.threshold_xyz).mean() * opt.lambda_xyz
-        loss_dict["scale"] = F.relu(gaussians.scaling_activation(gaussians._scaling[vis]) - opt.threshold_scale
-                                    ).norm(dim=1).mean() * opt.lambda_scale
+        # means over the visible Gaussians (s2_registration.py:262-265 index with [visibility_filter]); written with
+        # masks so that nothing depends on a host-side count -- same values, and the step stays graph-capturable
+        visf = vis.to(image.dtype)
+        n_vis = visf.sum()
+        loss_dict["xyz"] = (F.relu(gaussians._xyz.norm(dim=1) - opt.threshold_xyz) * visf).sum() / n_vis * opt.lambda_xyz
+        loss_dict["scale"] = (F.relu(gaussians.scaling_activation(gaussians._scaling) - opt.threshold_scale
+                                     ).norm(dim=1) * visf).sum() / n_vis * opt.lambda_scale
     loss = sum(loss_dict.values())
     loss.backward()
     with torch.no_grad():
+        graph_opt = isinstance(gaussians.optimizer, GraphAdam)
+        hdr = R.last_header() if graph_opt else None            # {num_rendered, overflow} of this step's forward
         if first_frame_template and track_densification:
-            gaussians.max_radii2D[vis] = torch.max(gaussians.max_radii2D[vis], radii[vis].to(gaussians.max_radii2D.dtype))
-            gaussians.add_densification_stats(vsp, vis)
+            mr = gaussians.max_radii2D
+            new_mr = torch.where(vis, torch.max(mr, radii.to(mr.dtype)), mr)
+            ok = None
+            if hdr is not None:                                  # a replayed step that overflowed changes nothing
+                ok = (hdr[1] == 0).to(gaussians.denom.dtype)
+                new_mr = torch.where(hdr[1] == 0, new_mr, mr)
+            mr.copy_(new_mr)
+            gaussians.add_densification_stats(vsp, vis, ok=ok)
         if optimizer_step and gaussians.optimizer is not None:
-            gaussians.optimizer.step()
+            if graph_opt:
+                gaussians.optimizer.step(guard=hdr[1:2])
+            else:
+                gaussians.optimizer.step()
             gaussians.optimizer.zero_grad()
     loss_dict["loss"] = loss.detach()
     loss_dict["render_pkg"] = pkg
@@ -86,3 +103,95 @@ def appearance_step(gaussians, net: Callable, viewpoint_cam, gt_image, mask, bg,
     loss_dict["loss"] = loss.detach()
     loss_dict["render_pkg"] = pkg
     return loss_dict
+
+
+class GraphedRegistrationStep:
+    """The s2 inner iteration (registration_step above: bind -> render -> L1/SSIM [+ hinges] -> backward ->
+    densification stats -> Adam) captured ONCE into a hipGraph and replayed per iteration.
+
+    The reference's loop is launch- and sync-bound on a fast GPU: ~60 small kernels and several host round trips
+    per iteration for ~1 ms of GPU work.  A replay is one graph launch; camera, ground truth and mask are copied
+    into static buffers in front of it; the learning rates live on the device (GraphAdam.push_lr).  The rasterizer
+    runs with the binning capacity learnt during the eager warm-up; if a replayed step overflows it, the guarded
+    kernels leave parameters, moments and statistics untouched, and this class grows the capacity, re-captures and
+    replays the step -- so results never depend on the capacity guess.
+
+    gaussians.optimizer must be a GraphAdam (ggsplat.adam).  Camera objects need world_view_transform,
+    full_proj_transform, camera_center, FoVx, FoVy (scene/cameras.py attributes)."""
+
+    def __init__(self, gaussians, W: int, H: int, bg, opt=DEFAULT_OPT, pipe=DEFAULT_PIPE,
+                 first_frame_template: bool = True, track_densification: bool = True, use_mask: bool = True,
+                 capacity_slack: float = 1.0):
+        if not isinstance(gaussians.optimizer, GraphAdam):
+            raise TypeError("GraphedRegistrationStep needs gaussians.optimizer to be a ggsplat.adam.GraphAdam")
+        dev = gaussians._xyz.device
+        self.g, self.opt, self.pipe, self.bg = gaussians, opt, pipe, bg
+        self.fft, self.track = first_frame_template, track_densification
+        self.cam = SimpleNamespace(
+            image_height=H, image_width=W, world_view_transform=torch.zeros(4, 4, device=dev),
+            full_proj_transform=torch.zeros(4, 4, device=dev), camera_center=torch.zeros(3, device=dev),
+            tanfov=torch.zeros(1, 2, device=dev))
+        self.gt = torch.zeros(3, H, W, device=dev)
+        self.mask = torch.ones(1, H, W, device=dev) if use_mask else None
+        self._tan_host = torch.zeros(1, 2).pin_memory()
+        self._hdr_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.out: Dict[str, torch.Tensor] = {}
+        self.recaptures = 0
+        self._slack = float(capacity_slack)     # applied once to the learnt capacity (< 1 exercises the recovery path)
+
+    def _load(self, cam, gt_image, mask):
+        import math
+        c = self.cam
+        c.world_view_transform.copy_(cam.world_view_transform, non_blocking=True)
+        c.full_proj_transform.copy_(cam.full_proj_transform, non_blocking=True)
+        c.camera_center.copy_(cam.camera_center, non_blocking=True)
+        self._tan_host[0, 0], self._tan_host[0, 1] = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        c.tanfov.copy_(self._tan_host, non_blocking=True)
+        self.gt.copy_(gt_image, non_blocking=True)
+        if self.mask is not None and mask is not None:
+            self.mask.copy_(mask.reshape(self.mask.shape), non_blocking=True)
+
+    def _body(self, optimizer_step: bool, track: bool):
+        d = registration_step(self.g, self.cam, self.gt, self.mask, self.bg, self.opt, self.pipe,
+                              first_frame_template=self.fft, track_densification=track,
+                              optimizer_step=optimizer_step, fused_loss=True)
+        d.pop("render_pkg", None)
+        return d
+
+    def _capture(self):
+        g = self.g
+        # eager warm-up on a side stream: learns the binning capacity, leaves parameters and statistics alone
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            self._body(optimizer_step=False, track=False)
+            g.optimizer.zero_grad()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        if self._slack != 1.0:
+            R.grow_capacity(self._slack)
+            self._slack = 1.0
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            out = self._body(optimizer_step=True, track=self.track)
+            self._hdr_dev = R.last_header()
+        self.out = {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
+
+    def __call__(self, cam, gt_image, mask=None) -> Dict[str, torch.Tensor]:
+        """One optimisation step.  Returns device scalars {"loss", "img", "ssim", ...} (overwritten by the next call)."""
+        self._load(cam, gt_image, mask)
+        if self.graph is None:
+            self._capture()
+            # the capture itself does not execute anything: fall through to the first replay
+        while True:
+            self.graph.replay()
+            self._hdr_host.copy_(self._hdr_dev, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            if int(self._hdr_host[1]) == 0:
+                return self.out
+            # the static binning capacity was too small for this view: nothing was updated (guarded kernels)
+            R.grow_capacity(2.0)
+            self.recaptures += 1
+            self.graph = None
+            self._capture()

@@ -223,11 +223,14 @@ class MeshGaussianModel:
             groups = [{"params": [self.mesh.v], "lr": pos_lr, "name": "vertex"}]
         self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
 
-    def add_densification_stats(self, viewspace_point_tensor, update_filter):
-        """scene/gaussian_model.py:410-412."""
-        self.xyz_gradient_accum[update_filter] += torch.norm(viewspace_point_tensor.grad[update_filter, :2],
-                                                             dim=-1, keepdim=True)
-        self.denom[update_filter] += 1
+    def add_densification_stats(self, viewspace_point_tensor, update_filter, ok=None):
+        """scene/gaussian_model.py:410-412, written with masks instead of boolean indexing (no host sync, so the
+        step can be captured into a graph).  ok: optional device scalar (0/1) that voids the update."""
+        f = update_filter.unsqueeze(1).to(self.denom.dtype)
+        if ok is not None:
+            f = f * ok
+        self.xyz_gradient_accum += torch.norm(viewspace_point_tensor.grad[:, :2], dim=-1, keepdim=True) * f
+        self.denom += f
 
     # ---- visibility (SURVEY.md section 8f #4) -------------------------------------------------------------
     def get_anchor_points(self) -> torch.Tensor:

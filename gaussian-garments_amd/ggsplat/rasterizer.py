@@ -8,7 +8,10 @@ the native backward.  Call site being served: gaussian_renderer/__init__.py:54,
   * the native side is a C ABI over caller-allocated workspaces (no resize callback);
   * one call can batch V views (grid dimension = view) over the same Gaussians;
   * the only host sync is one 16-byte header read-back per call after the tile scan
-    (num_rendered + overflow flag), never per kernel; the compositing is queued behind it.
+    (num_rendered + overflow flag), never per kernel; the compositing is queued behind it;
+  * while the current stream is being captured into a hipGraph (torch.cuda.graph) there is NO sync: the call
+    uses the binning capacity learnt by earlier eager calls, and the overflow flag stays on the device
+    (`last_header()`), where the guarded optimiser kernels (ggsplat.adam) and the graph owner read it.
 """
 from __future__ import annotations
 
@@ -22,6 +25,19 @@ from ._lib import GgsParams, check, lib, ptr
 
 # running estimate of the binning capacity per (device, P, W, H, V); grows on overflow
 _cap_hint: Dict[Tuple, int] = {}
+# bin header {num_rendered, overflow} (device int64[2]) of the most recent forward_views call
+_last_header: Optional[torch.Tensor] = None
+
+
+def last_header() -> Optional[torch.Tensor]:
+    """Device int64[2] = GgsBinHeader {num_rendered, overflow} of the most recent forward (aliases its workspace)."""
+    return _last_header
+
+
+def grow_capacity(factor: float = 2.0) -> None:
+    """Enlarge every learnt binning capacity (a captured step reported overflow: re-capture after this)."""
+    for k in list(_cap_hint):
+        _cap_hint[k] = int(_cap_hint[k] * factor) + 1024
 
 
 def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -95,12 +111,29 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
     alpha = torch.empty(V, H, W, device=dev, dtype=torch.float32)
     radii = torch.empty(V, P, device=dev, dtype=torch.int32)
 
+    global _last_header
     key = (dev.index, P, W, H, V)
     cap = _cap_hint.get(key, max(8 * P * V, 1 << 16))
     stream = _stream_ptr(dev)
     host = _pinned_header(dev)
     geom = img = None
-    while True:
+    capturing = torch.cuda.is_current_stream_capturing()
+    while capturing:        # one pass: static capacity, no host sync, overflow flag left on the device
+        if key not in _cap_hint:
+            raise _lib.GgsError("ggsplat: run this configuration eagerly once before capturing it into a graph "
+                                "(the binning capacity is learnt from an eager call)")
+        gsz, isz, bsz = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        check(L.ggs_workspace_sizes(C.byref(prm), cap, C.byref(gsz), C.byref(isz), C.byref(bsz)), "ggs_workspace_sizes")
+        geom = torch.empty(gsz.value, device=dev, dtype=torch.uint8)
+        img = torch.empty(isz.value, device=dev, dtype=torch.uint8)
+        binb = torch.empty(bsz.value, device=dev, dtype=torch.uint8)
+        args = (C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales),
+                ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov), ptr(geom),
+                ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha), ptr(radii), stream)
+        check(L.ggs_forward(*args), "ggs_forward")
+        n = -1
+        break
+    while not capturing:
         gsz, isz, bsz = C.c_size_t(), C.c_size_t(), C.c_size_t()
         check(L.ggs_workspace_sizes(C.byref(prm), cap, C.byref(gsz), C.byref(isz), C.byref(bsz)), "ggs_workspace_sizes")
         if geom is None:
@@ -119,9 +152,11 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
         if not overflow:
             break
         cap = int(n * 1.25) + 1024             # n is exact: one retry is always enough
-    _cap_hint[key] = max(cap if n * 2 <= cap else int(n * 2), 1 << 16)
-    # phase 2: scatter + sort + composite, queued without waiting
-    check(L.ggs_forward_render(*args), "ggs_forward_render")
+    if not capturing:
+        _cap_hint[key] = max(cap if n * 2 <= cap else int(n * 2), 1 << 16)
+        # phase 2: scatter + sort + composite, queued without waiting
+        check(L.ggs_forward_render(*args), "ggs_forward_render")
+    _last_header = binb[:16].view(torch.int64)
     st = None
     if keep_state:
         st = ForwardState()
@@ -194,7 +229,9 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, settings):
         dev = means3D.device
-        tanfov = tanfov_tensor(settings.tanfovx, settings.tanfovy, dev)
+        tanfov = getattr(settings, "tanfov", None)      # device [1,2] of a static (graph-captured) camera
+        if tanfov is None:
+            tanfov = tanfov_tensor(settings.tanfovx, settings.tanfovy, dev)
         color, radii, depth, alpha, st = forward_views(
             means3D, opacities, sh, colors_precomp, scales, rotations, cov3Ds_precomp,
             view=settings.viewmatrix, proj=settings.projmatrix, campos=settings.campos, tanfov=tanfov,

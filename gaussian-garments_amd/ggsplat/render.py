@@ -8,6 +8,7 @@ render() works unmodified as well; this mirror exists so the inner-step harness 
 not need the reference tree (it never travels to the GPU box).
 """
 import math
+from types import SimpleNamespace
 
 import torch
 
@@ -17,6 +18,13 @@ from .sh import eval_sh
 
 
 def _settings(cam, pc_sh_degree, pipe, bg_color, scaling_modifier):
+    tf = getattr(cam, "tanfov", None)
+    if tf is not None:      # static camera of a captured step: the tangents live in a device tensor [1,2]
+        return SimpleNamespace(
+            image_height=int(cam.image_height), image_width=int(cam.image_width), tanfov=tf, tanfovx=None, tanfovy=None,
+            bg=bg_color, scale_modifier=scaling_modifier, viewmatrix=cam.world_view_transform,
+            projmatrix=cam.full_proj_transform, sh_degree=pc_sh_degree, campos=cam.camera_center, prefiltered=False,
+            debug=pipe.debug)
     return GaussianRasterizationSettings(
         image_height=int(cam.image_height), image_width=int(cam.image_width),
         tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5), bg=bg_color,

@@ -203,6 +203,23 @@ int ggs_upfirdn2d(int major, int in_h, int in_w, int minor, const float* input, 
                   float* out, void* stream);
 
 /*
+ * Optimiser update of the inner loops as graph-capturable kernels -- what the reference does with
+ * torch.optim.Adam(l, lr=0.0, eps=1e-15) (scene/mesh_gaussian_model.py:375, gaussian_model.py:165, avatar_net.py:50;
+ * stepped at s2_registration.py:316-318, s3_appearance.py:143-145).  Same arithmetic as torch's single-tensor Adam
+ * (no amsgrad, no weight decay), but step count / bias corrections (`state`, ggs_adam_state_bytes() bytes, zeroed by
+ * the caller) and the learning rate (`lr`, one float) live in DEVICE memory, so a whole optimisation step can be
+ * replayed as a hipGraph while the host moves the xyz schedule.  `guard` (may be NULL) points at a device u64 --
+ * GgsBinHeader.overflow of the forward of the same step: non-zero => tick and step do nothing.
+ *   ggs_adam_tick: once per optimiser step, before the per-tensor updates: step += 1, refresh bias corrections.
+ *   ggs_adam_step: one tensor of n floats (param / grad / exp_avg / exp_avg_sq 16-byte aligned).
+ * betas / eps are doubles because torch forms 1 - beta in double before rounding to fp32 (1 - 0.999f is off by 1.3e-5).
+ */
+size_t ggs_adam_state_bytes(void);
+int ggs_adam_tick(void* state, double beta1, double beta2, const void* guard, void* stream);
+int ggs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* lr,
+                  double beta1, double beta2, double eps, const void* state, const void* guard, void* stream);
+
+/*
  * Visibility of mesh-bound Gaussians from one camera -- replaces the per-iteration open3d / Embree
  * ray cast of AvatarGaussianModel.get_visible_mask (scene/avatar_gaussian_model.py:227-263): ray i goes from
  * `cam` [3] (device) to targets[i] (the Gaussian's anchor on its face); mask[i] = 1 iff the FIRST triangle the

@@ -1,0 +1,118 @@
+"""Graph-captured inner step (the caller of the hot path): GraphAdam against torch.optim.Adam, the
+overflow guard, and GraphedRegistrationStep (one hipGraph replay per s2 iteration) against the eager
+registration_step with torch's Adam on the same cameras -- parameters, moments-driven updates, densification
+statistics and loss terms after several iterations."""
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from ggsplat import synthetic as S
+
+pytestmark = pytest.mark.gpu
+W, H = 96, 80
+
+
+def test_graph_adam_matches_torch_adam():
+    from ggsplat.adam import GraphAdam
+    g = torch.Generator().manual_seed(1)
+    shapes = [(1000, 3), (1000, 1, 3), (777,), (5, 4)]
+    a = [torch.randn(*s, generator=g).cuda().requires_grad_(True) for s in shapes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    lrs = [1.6e-4, 2.5e-3, 5e-2, 1e-3]
+    ref = torch.optim.Adam([{"params": [p], "lr": lr} for p, lr in zip(b, lrs)], lr=0.0, eps=1e-15)
+    opt = GraphAdam([{"params": [p], "lr": lr} for p, lr in zip(a, lrs)], lr=0.0, eps=1e-15)
+    for it in range(6):
+        for pa, pb in zip(a, b):
+            gr = torch.randn(pa.shape, generator=g).cuda() * (10.0 ** (it - 3))
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        if it == 3:                                   # schedule update between steps
+            ref.param_groups[0]["lr"] = opt.param_groups[0]["lr"] = 7e-5
+            opt.push_lr()
+        ref.step()
+        opt.step()
+    assert opt.step_count == 6
+    for pa, pb in zip(a, b):
+        assert torch.allclose(pa, pb, rtol=2e-6, atol=1e-7), float((pa - pb).abs().max())
+        for k in ("exp_avg", "exp_avg_sq"):
+            x, y = opt.state[pa][k], ref.state[pb][k]
+            assert torch.allclose(x, y, rtol=1e-5, atol=1e-6 * float(y.abs().max())), (k, float((x - y).abs().max()))
+
+
+def test_graph_adam_guard_voids_the_step():
+    from ggsplat.adam import GraphAdam
+    p = torch.randn(1001).cuda().requires_grad_(True)
+    p.grad = torch.randn(1001).cuda()
+    before = p.detach().clone()
+    opt = GraphAdam([{"params": [p], "lr": 1e-2}])
+    guard = torch.ones(1, dtype=torch.int64, device="cuda")
+    opt.step(guard=guard)
+    assert torch.equal(p.detach(), before) and opt.step_count == 0
+    assert float(opt.state[p]["exp_avg"].abs().max()) == 0.0
+    guard.zero_()
+    opt.step(guard=guard)
+    assert opt.step_count == 1 and not torch.equal(p.detach(), before)
+
+
+def _scene(seed=0):
+    v, f = S.skirt_mesh(24, 40, r_top=0.30, r_bottom=0.5, height=0.8, jitter=2e-3, seed=seed)
+    params = S.skirt_gaussian_params(f.shape[0], sh_degree=0, seed=seed)
+    cams = S.rig_cameras(n_rings=2, n_az=3, radius=2.2, width=W, height=H, f=70.0, seed=seed)
+    for cam in cams:
+        for n in ("world_view_transform", "full_proj_transform", "camera_center"):
+            setattr(cam, n, getattr(cam, n).cuda())
+    g = torch.Generator().manual_seed(seed + 9)
+    gts = [torch.rand(3, H, W, generator=g).cuda() for _ in cams]
+    masks = [(torch.rand(1, H, W, generator=g) > 0.2).float().cuda() for _ in cams]
+    return v, f, params, cams, gts, masks
+
+
+def _model(v, f, params, opt, graph: bool):
+    from ggsplat.adam import GraphAdam
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
+    m.training_setup(opt, is_ff=True)
+    if graph:
+        m.optimizer = GraphAdam(m.optimizer.param_groups, lr=0.0, eps=1e-15)
+    return m
+
+
+@pytest.mark.parametrize("slack", [1.0, 0.002])
+def test_graphed_registration_step_matches_eager(slack):
+    """slack 0.002: the first capture runs with a binning capacity far too small -> the replay overflows, the guarded
+    kernels change nothing, the step re-captures and replays; the trajectory must be the same."""
+    from ggsplat import rasterizer as R
+    from ggsplat.inner_step import DEFAULT_OPT, GraphedRegistrationStep, registration_step
+    opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "threshold_xyz": 0.3, "threshold_scale": 0.02})
+    v, f, params, cams, gts, masks = _scene()
+    bg = torch.zeros(3, device="cuda")
+    eager, graphed = _model(v, f, params, opt, False), _model(v, f, params, opt, True)
+    R._cap_hint.clear()
+    step = GraphedRegistrationStep(graphed, W, H, bg, opt=opt, capacity_slack=slack)
+    names = ["_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"]
+    order = [0, 3, 1, 5, 2, 4, 0]
+    for it, ci in enumerate(order):
+        if it == 4:                                   # learning-rate schedule moves between iterations
+            for m in (eager, graphed):
+                m.optimizer.param_groups[0]["lr"] *= 0.5
+            graphed.optimizer.push_lr()
+        ref = registration_step(eager, cams[ci], gts[ci], masks[ci], bg, opt=opt, fused_loss=True)
+        out = step(cams[ci], gts[ci], masks[ci])
+        for k in ("img", "ssim", "xyz", "scale", "loss"):
+            assert abs(float(out[k]) - float(ref[k])) <= 1e-4 * max(1.0, abs(float(ref[k]))), (it, k)
+    assert step.recaptures == (0 if slack == 1.0 else 1)
+    assert graphed.optimizer.step_count == len(order)
+    # Both sides run the same kernels; the only difference is the order of the float atomics.  Adam with eps 1e-15
+    # turns a gradient whose sign is decided by that rounding noise into a full +-lr step, so a handful of elements
+    # may legitimately differ: require 99.5 % of every tensor within tolerance and a tiny mean deviation.
+    def close(a, b, rtol, atol, what):
+        ok = (a - b).abs() <= atol + rtol * b.abs()
+        assert float(ok.float().mean()) >= 0.995, (what, float(ok.float().mean()), float((a - b).abs().max()))
+        assert float((a - b).abs().mean()) <= 1e-5, (what, float((a - b).abs().mean()))
+
+    for n in names:
+        close(getattr(graphed, n).detach(), getattr(eager, n).detach(), 1e-4, 2e-6, n)
+    close(graphed.mesh.v.detach(), eager.mesh.v.detach(), 1e-4, 2e-6, "mesh.v")
+    close(graphed.xyz_gradient_accum, eager.xyz_gradient_accum, 1e-3, 1e-7, "xyz_gradient_accum")
+    assert torch.equal(graphed.denom, eager.denom)
+    assert torch.equal(graphed.max_radii2D, eager.max_radii2D)

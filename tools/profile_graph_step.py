@@ -1,0 +1,32 @@
+"""Graph-replayed s2 inner step at config 2 (100k Gaussians, 1080p, one view per iteration) -- run under
+rocprofv3 --kernel-trace to see where the GPU time of one iteration goes."""
+import sys, os, time, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "gaussian-garments_amd"))
+from ggsplat import synthetic as S
+from ggsplat.adam import GraphAdam
+from ggsplat.inner_step import DEFAULT_OPT, GraphedRegistrationStep
+from ggsplat.mesh_gaussian_model import MeshGaussianModel
+dev = "cuda"
+W, H = 1920, 1080
+v, f = S.skirt_mesh(); p = S.skirt_gaussian_params(f.shape[0], 0)
+m = MeshGaussianModel.from_tensors(v, f, p, 0, device=dev)
+m.training_setup(DEFAULT_OPT, is_ff=True)
+m.optimizer = GraphAdam(m.optimizer.param_groups, lr=0.0, eps=1e-15)
+cams = S.rig_cameras(device=dev)[:16]
+for c in cams:
+    for name in ("world_view_transform", "full_proj_transform", "camera_center"):
+        setattr(c, name, getattr(c, name).to(dev))
+bg = torch.zeros(3, device=dev)
+gt = torch.rand(3, H, W, device=dev); mask = (torch.rand(1, H, W, device=dev) > 0.1).float()
+step = GraphedRegistrationStep(m, W, H, bg)
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+for c in cams[:2]:
+    step(c, gt, mask)
+torch.cuda.synchronize()
+t = time.perf_counter()
+for i in range(n):
+    step(cams[i % len(cams)], gt, mask)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t
+print(f"graphed s2 step: {n/dt:.1f} it/s, {dt/n*1e3:.3f} ms/it, recaptures {step.recaptures}")
