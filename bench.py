@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--n-around", type=int, default=200)
     ap.add_argument("--n-rows", type=int, default=250)
-    ap.add_argument("--cpu-views", type=int, default=2, help="views of the workload timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-views", type=int, default=40, help="views of the workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--loop-views", type=int, default=16, help="views timed through the per-view drop-in render() loop")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for functional tests)")
@@ -167,6 +167,9 @@ def main():
             acc_ms = [a + b for a, b in zip(acc_ms, ms)]
             P_vis = float((radii > 0).sum().item()) / chunk
             N_chunk = st.num_rendered
+            # blended splats per pixel (n_contrib = position of the last contributor in the tile's list)
+            nc = st.img[st.img.numel() // 2:].view(torch.int32)[:chunk * H * W]
+            mean_contrib = float(nc.float().mean().item())
             del st
         L.ggs_profile_enable(0)
         kern_ms = {k: v / reps for k, v in zip(KERNELS, acc_ms)}
@@ -201,7 +204,7 @@ def main():
 
         # ---- per-view drop-in loop (render() + autograd, one camera per call like the reference) ----
         loop_vps = step_vps = graph_vps = None
-        if args.loop_views > 0:
+        if args.loop_views > 0 and world == 1:
             from ggsplat.render import render
             from types import SimpleNamespace
             pipe = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
@@ -260,7 +263,7 @@ def main():
 
         # ---- CPU baseline: the C oracle on the host cores, bounded sample of the same views ----
         cpu = None
-        if args.cpu_views > 0:
+        if args.cpu_views > 0 and world == 1:       # ~10 s of host work; reported at N=1 only
             from oracle.c_oracle import COracle, build as build_oracle
             build_oracle()
             ci = {k: v.cpu() for k, v in inputs.items()}
@@ -290,7 +293,9 @@ def main():
             "config": {"workload": f"{Fn} mesh-bound Gaussians (skirt tube, MeshGaussianModel), {len(all_cams)} synthetic "
                                    f"{W}x{H} cameras, SH degree {args.sh_degree}, fwd+bwd with dense dL/dimage",
                        "views_per_step": n_views_total, "views_per_launch": chunk, "parallelism": f"views sharded x{world}",
-                       "num_rendered_per_view": round(N_view, 1), "visible_per_view": round(P_vis, 1)},
+                       "num_rendered_per_view": round(N_view, 1), "visible_per_view": round(P_vis, 1),
+                       "mean_list_length_per_pixel": round(N_view / T, 2),
+                       "mean_last_contributor_per_pixel": round(mean_contrib, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
             "per_view_loop_views_per_sec": None if loop_vps is None else round(loop_vps, 2),
             "s2_inner_step_iters_per_sec": None if step_vps is None else round(step_vps, 2),

@@ -67,60 +67,97 @@ __global__ __launch_bounds__(256) void ggs_k_loss_stats(LossArgs a) {
     const float* gt = a.gt + ((size_t)v * 3 + ch) * HW;
     const float* mask = a.mask ? a.mask + (size_t)v * HW : nullptr;
 
+    // Tile + halo into LDS.  All global loads of a thread are issued before the first use (7 independent elements
+    // per thread, fully unrolled): with ~3 waves per SIMD the kernel is otherwise bound by 7 serial HBM round trips.
     float l1 = 0.f;
-    for (int i = tid; i < LI * LI; i += 256) {
-        const int r = i / LI, c = i % LI;
-        const int y = oy + r - LH, x = ox + c - LH;
-        float xv = 0.f, yv = 0.f;
-        if (x >= 0 && x < a.W && y >= 0 && y < a.H) {
-            const size_t p = (size_t)y * a.W + x;
-            const float m = mask ? mask[p] : 1.f;
-            xv = img[p] * m; yv = gt[p] * m;
-            // the L1 term is summed over the tile's own pixels only (not the halo)
-            if (r >= LH && r < LH + LT && c >= LH && c < LH + LT) l1 += fabsf(xv - yv);
-        }
-        sx[r][c] = xv; sy[r][c] = yv;
-    }
-    __syncthreads();
-    // horizontal pass: LI rows x LT columns
-    for (int i = tid; i < LI * LT; i += 256) {
-        const int r = i / LT, c = i % LT;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    {
+        constexpr int NL = (LI * LI + 255) / 256;
+        float xr[NL], yr[NL], mr[NL];
+        bool in[NL];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float g = G11[k], xv = sx[r][c + k], yv = sy[r][c + k];
-            m1 = fmaf(g, xv, m1); m2 = fmaf(g, yv, m2);
-            e11 = fmaf(g, xv * xv, e11); e22 = fmaf(g, yv * yv, e22); e12 = fmaf(g, xv * yv, e12);
+        for (int j = 0; j < NL; ++j) {
+            const int i = tid + j * 256;
+            const int r = i / LI, c = i % LI;
+            const int y = oy + r - LH, x = ox + c - LH;
+            in[j] = i < LI * LI && x >= 0 && x < a.W && y >= 0 && y < a.H;
+            const size_t p = in[j] ? (size_t)y * a.W + x : 0;
+            xr[j] = in[j] ? img[p] : 0.f;
+            yr[j] = in[j] ? gt[p] : 0.f;
+            mr[j] = (in[j] && mask) ? mask[p] : 1.f;
         }
-        hh[0][r][c] = m1; hh[1][r][c] = m2; hh[2][r][c] = e11; hh[3][r][c] = e22; hh[4][r][c] = e12;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int i = tid + j * 256;
+            if (i >= LI * LI) continue;
+            const int r = i / LI, c = i % LI;
+            const float xv = xr[j] * mr[j], yv = yr[j] * mr[j];
+            // the L1 term is summed over the tile's own pixels only (not the halo)
+            if (in[j] && r >= LH && r < LH + LT && c >= LH && c < LH + LT) l1 += fabsf(xv - yv);
+            sx[r][c] = xv; sy[r][c] = yv;
+        }
     }
     __syncthreads();
-    // vertical pass + SSIM map + derivative maps
+    // horizontal pass, register blocked: thread = (row, 8 adjacent output columns) reads its 18 inputs of x and y once
+    // (36 LDS reads for 8 outputs x 5 maps instead of 176) -- the kernel is bound by LDS latency, not by the FMAs.
+    // Accumulation order per output is unchanged (taps 0..10).
+    {
+        const int r = tid >> 2, c0 = (tid & 3) * 8;
+        if (r < LI) {
+            float xv[18], yv[18];
+#pragma unroll
+            for (int j = 0; j < 18; ++j) { xv[j] = sx[r][c0 + j]; yv[j] = sy[r][c0 + j]; }
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    const float g = G11[k], x = xv[o + k], y = yv[o + k];
+                    m1 = fmaf(g, x, m1); m2 = fmaf(g, y, m2);
+                    e11 = fmaf(g, x * x, e11); e22 = fmaf(g, y * y, e22); e12 = fmaf(g, x * y, e12);
+                }
+                hh[0][r][c0 + o] = m1; hh[1][r][c0 + o] = m2; hh[2][r][c0 + o] = e11; hh[3][r][c0 + o] = e22;
+                hh[4][r][c0 + o] = e12;
+            }
+        }
+    }
+    __syncthreads();
+    // vertical pass + SSIM map + derivative maps: thread = (column, 4 adjacent output rows), 14 reads per map
     float ssum = 0.f;
     float* dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW;
-    for (int i = tid; i < LT * LT; i += 256) {
-        const int r = i / LT, c = i % LT;
-        const int y = oy + r, x = ox + c;
-        if (x >= a.W || y >= a.H) continue;
-        float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+    {
+        const int c = tid & 31, r0 = (tid >> 5) * 4;
+        const int x = ox + c;
+        float col[5][14];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float g = G11[k];
-            m1 = fmaf(g, hh[0][r + k][c], m1); m2 = fmaf(g, hh[1][r + k][c], m2);
-            e11 = fmaf(g, hh[2][r + k][c], e11); e22 = fmaf(g, hh[3][r + k][c], e22);
-            e12 = fmaf(g, hh[4][r + k][c], e12);
+        for (int m = 0; m < 5; ++m)
+#pragma unroll
+            for (int j = 0; j < 14; ++j) col[m][j] = hh[m][r0 + j][c];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int y = oy + r0 + o;
+            if (x >= a.W || y >= a.H) continue;
+            float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float g = G11[k];
+                m1 = fmaf(g, col[0][o + k], m1); m2 = fmaf(g, col[1][o + k], m2);
+                e11 = fmaf(g, col[2][o + k], e11); e22 = fmaf(g, col[3][o + k], e22);
+                e12 = fmaf(g, col[4][o + k], e12);
+            }
+            const float v1 = e11 - m1 * m1, v2 = e22 - m2 * m2, cv = e12 - m1 * m2;
+            const float A1 = 2.f * m1 * m2 + SSIM_C1, A2 = 2.f * cv + SSIM_C2;
+            const float B1 = m1 * m1 + m2 * m2 + SSIM_C1, B2 = v1 + v2 + SSIM_C2;
+            // two v_rcp_f32 (1 ulp) instead of five IEEE divisions (~10 instructions each); B1, B2 >= C1, C2 > 0
+            const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
+            const float inv = iB1 * iB2;
+            const float S = A1 * A2 * inv;
+            ssum += S;
+            const size_t p = (size_t)y * a.W + x;
+            // total derivative w.r.t. mu1 (through A1, A2 = 2(E12 - m1 m2) + C2, B1, B2 = E11 - m1^2 + ...)
+            dm[p] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * iB1 + 2.f * m1 * S * iB2;
+            dm[HW + p] = -S * iB2;                // d/dE[xx]
+            dm[2 * HW + p] = 2.f * A1 * inv;      // d/dE[xy]
         }
-        const float v1 = e11 - m1 * m1, v2 = e22 - m2 * m2, cv = e12 - m1 * m2;
-        const float A1 = 2.f * m1 * m2 + SSIM_C1, A2 = 2.f * cv + SSIM_C2;
-        const float B1 = m1 * m1 + m2 * m2 + SSIM_C1, B2 = v1 + v2 + SSIM_C2;
-        const float inv = 1.f / (B1 * B2);
-        const float S = A1 * A2 * inv;
-        ssum += S;
-        const size_t p = (size_t)y * a.W + x;
-        // total derivative w.r.t. mu1 (through A1, A2 = 2(E12 - m1 m2) + C2, B1, B2 = E11 - m1^2 + ...)
-        dm[p] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S / B1 + 2.f * m1 * S / B2;
-        dm[HW + p] = -S / B2;                 // d/dE[xx]
-        dm[2 * HW + p] = 2.f * A1 * inv;      // d/dE[xy]
     }
     l1 = block_sum(l1, s_red);
     ssum = block_sum(ssum, s_red);
@@ -139,26 +176,46 @@ __global__ __launch_bounds__(256) void ggs_k_loss_grad(LossArgs a) {
     const int ox = blockIdx.x * LT, oy = blockIdx.y * LT;
     const size_t HW = (size_t)a.H * a.W;
     const float* dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW;
-    for (int i = tid; i < LI * LI; i += 256) {
-        const int r = i / LI, c = i % LI;
-        const int y = oy + r - LH, x = ox + c - LH;
-        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-        if (x >= 0 && x < a.W && y >= 0 && y < a.H) {
-            const size_t p = (size_t)y * a.W + x;
-            d0 = dm[p]; d1 = dm[HW + p]; d2 = dm[2 * HW + p];
+    {   // all global loads of a thread in flight at once (see pass A)
+        constexpr int NL = (LI * LI + 255) / 256;
+        float d0[NL], d1[NL], d2[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int i = tid + j * 256;
+            const int r = i / LI, c = i % LI;
+            const int y = oy + r - LH, x = ox + c - LH;
+            const bool in = i < LI * LI && x >= 0 && x < a.W && y >= 0 && y < a.H;
+            const size_t p = in ? (size_t)y * a.W + x : 0;
+            d0[j] = in ? dm[p] : 0.f; d1[j] = in ? dm[HW + p] : 0.f; d2[j] = in ? dm[2 * HW + p] : 0.f;
         }
-        sd[0][r][c] = d0; sd[1][r][c] = d1; sd[2][r][c] = d2;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int i = tid + j * 256;
+            if (i >= LI * LI) continue;
+            const int r = i / LI, c = i % LI;
+            sd[0][r][c] = d0[j]; sd[1][r][c] = d1[j]; sd[2][r][c] = d2[j];
+        }
     }
     __syncthreads();
-    for (int i = tid; i < LI * LT; i += 256) {
-        const int r = i / LT, c = i % LT;
-        float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+    {   // horizontal, register blocked like pass A
+        const int r = tid >> 2, c0 = (tid & 3) * 8;
+        if (r < LI) {
+            float d[3][18];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float g = G11[k];
-            h0 = fmaf(g, sd[0][r][c + k], h0); h1 = fmaf(g, sd[1][r][c + k], h1); h2 = fmaf(g, sd[2][r][c + k], h2);
+            for (int m = 0; m < 3; ++m)
+#pragma unroll
+                for (int j = 0; j < 18; ++j) d[m][j] = sd[m][r][c0 + j];
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                float h0 = 0.f, h1 = 0.f, h2 = 0.f;
+#pragma unroll
+                for (int k = 0; k < 11; ++k) {
+                    const float g = G11[k];
+                    h0 = fmaf(g, d[0][o + k], h0); h1 = fmaf(g, d[1][o + k], h1); h2 = fmaf(g, d[2][o + k], h2);
+                }
+                hh[0][r][c0 + o] = h0; hh[1][r][c0 + o] = h1; hh[2][r][c0 + o] = h2;
+            }
         }
-        hh[0][r][c] = h0; hh[1][r][c] = h1; hh[2][r][c] = h2;
     }
     __syncthreads();
     const float* img = a.img + ((size_t)v * 3 + ch) * HW;
@@ -166,23 +223,32 @@ __global__ __launch_bounds__(256) void ggs_k_loss_grad(LossArgs a) {
     const float* mask = a.mask ? a.mask + (size_t)v * HW : nullptr;
     float* out = a.dL_dimg + ((size_t)v * 3 + ch) * HW;
     const float w_l1 = a.w[2 * v] * a.inv_n, w_ssim = a.w[2 * v + 1] * a.inv_n;
-    for (int i = tid; i < LT * LT; i += 256) {
-        const int r = i / LT, c = i % LT;
-        const int y = oy + r, x = ox + c;
-        if (x >= a.W || y >= a.H) continue;
-        float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+    {
+        const int c = tid & 31, r0 = (tid >> 5) * 4;
+        const int x = ox + c;
+        float col[3][14];
 #pragma unroll
-        for (int k = 0; k < 11; ++k) {
-            const float g = G11[k];
-            f0 = fmaf(g, hh[0][r + k][c], f0); f1 = fmaf(g, hh[1][r + k][c], f1); f2 = fmaf(g, hh[2][r + k][c], f2);
+        for (int m = 0; m < 3; ++m)
+#pragma unroll
+            for (int j = 0; j < 14; ++j) col[m][j] = hh[m][r0 + j][c];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) {
+            const int y = oy + r0 + o;
+            if (x >= a.W || y >= a.H) continue;
+            float f0 = 0.f, f1 = 0.f, f2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < 11; ++k) {
+                const float g = G11[k];
+                f0 = fmaf(g, col[0][o + k], f0); f1 = fmaf(g, col[1][o + k], f1); f2 = fmaf(g, col[2][o + k], f2);
+            }
+            const size_t p = (size_t)y * a.W + x;
+            const float m = mask ? mask[p] : 1.f;
+            const float xv = img[p] * m, yv = gt[p] * m;
+            const float dssim = f0 + 2.f * xv * f1 + yv * f2;
+            const float df = xv - yv;
+            const float dl1 = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+            out[p] = m * (w_ssim * dssim + w_l1 * dl1);
         }
-        const size_t p = (size_t)y * a.W + x;
-        const float m = mask ? mask[p] : 1.f;
-        const float xv = img[p] * m, yv = gt[p] * m;
-        const float dssim = f0 + 2.f * xv * f1 + yv * f2;
-        const float df = xv - yv;
-        const float dl1 = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-        out[p] = m * (w_ssim * dssim + w_l1 * dl1);
     }
 }
 

@@ -1,0 +1,133 @@
+// ggs_regaux.hip -- everything of one s2 registration iteration that is neither rasterizer, photometric loss nor
+// optimiser, in two small kernels ("fused Adam + densification stats"):
+//   * the two hinge regularisers of the first-frame template and their gradients
+//       loss_xyz   = lambda_xyz   * mean_vis relu(|_xyz_i| - threshold_xyz)                (s2_registration.py:262-263)
+//       loss_scale = lambda_scale * mean_vis |relu(exp(_scaling_i) - threshold_scale)|_2   (s2_registration.py:264-265)
+//     (mean over the Gaussians with radii > 0), gradients ADDED to the local-parameter gradient buffers;
+//   * the chain rule through the opacity activation: dL/d_opacity = dL/dopacity * o (1 - o)  (scene/gaussian_model.py:107-108)
+//   * densification statistics: max_radii2D[vis] = max(., radii), xyz_gradient_accum[vis] += |dL/dmeans2D.xy|,
+//     denom[vis] += 1                                            (s2_registration.py:301-303, scene/gaussian_model.py:410-412)
+// In PyTorch this is ~45 elementwise / reduction / indexing kernels per iteration (and, with boolean indexing, two
+// host syncs); a captured iteration spends more time in those launches than in the rasterizer's forward.
+// HBM-bound, ~100 B per Gaussian.  `guard` as in ggs_adam.hip: statistics are left untouched when it is set.
+#include "ggs_kernels.h"
+
+namespace {
+
+struct RegArgs {
+    int P;
+    const float* xyz; const float* log_scaling; const int* radii; const float* dL_dmeans2D;
+    const float* opacity; const float* dL_dopacity; float* dL_dopacity_logit;
+    float thr_xyz, lam_xyz, thr_scale, lam_scale;
+    float* dL_dxyz; float* dL_dlog_scaling;
+    float* max_radii2D; float* xyz_gradient_accum; float* denom;
+    float* out_losses;           // {loss_xyz, loss_scale, n_visible}
+    float* sums;                 // scratch: {n_visible, sum hinge_xyz, sum hinge_scale}
+    const unsigned long long* guard;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_reg_reduce(RegArgs a) {
+    __shared__ float red[3][4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float n = 0.f, hx = 0.f, hs = 0.f;
+    if (i < a.P && a.radii[i] > 0) {
+        n = 1.f;
+        const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+        hx = fmaxf(sqrtf(x * x + y * y + z * z) - a.thr_xyz, 0.f);
+        const float s0 = fmaxf(expf(a.log_scaling[3 * i]) - a.thr_scale, 0.f);
+        const float s1 = fmaxf(expf(a.log_scaling[3 * i + 1]) - a.thr_scale, 0.f);
+        const float s2 = fmaxf(expf(a.log_scaling[3 * i + 2]) - a.thr_scale, 0.f);
+        hs = sqrtf(s0 * s0 + s1 * s1 + s2 * s2);
+    }
+    n = wave_sum(n); hx = wave_sum(hx); hs = wave_sum(hs);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) { red[0][w] = n; red[1][w] = hx; red[2][w] = hs; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float t = red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3];
+        if (t != 0.f) atomicAdd(&a.sums[threadIdx.x], t);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_reg_apply(RegArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const float n_vis = a.sums ? a.sums[0] : 0.f;
+    if (i == 0 && a.out_losses && a.sums) {
+        a.out_losses[0] = a.sums[1] / n_vis * a.lam_xyz;          // 0/0 = NaN like torch's mean over an empty selection
+        a.out_losses[1] = a.sums[2] / n_vis * a.lam_scale;
+        a.out_losses[2] = n_vis;
+    }
+    if (i >= a.P) return;
+    if (a.dL_dopacity_logit) {                                     // sigmoid backward
+        const float o = a.opacity[i];
+        a.dL_dopacity_logit[i] = a.dL_dopacity[i] * ((1.f - o) * o);
+    }
+    const bool vis = a.radii[i] > 0;
+    if (a.dL_dxyz && vis) {
+        const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+        const float nrm = sqrtf(x * x + y * y + z * z);
+        if (nrm > a.thr_xyz) {                                     // relu'(0) = 0; nrm > thr >= 0 here
+            const float c = a.lam_xyz / n_vis / nrm;
+            a.dL_dxyz[3 * i] += c * x; a.dL_dxyz[3 * i + 1] += c * y; a.dL_dxyz[3 * i + 2] += c * z;
+        }
+        const float e0 = expf(a.log_scaling[3 * i]), e1 = expf(a.log_scaling[3 * i + 1]), e2 = expf(a.log_scaling[3 * i + 2]);
+        const float s0 = fmaxf(e0 - a.thr_scale, 0.f), s1 = fmaxf(e1 - a.thr_scale, 0.f), s2 = fmaxf(e2 - a.thr_scale, 0.f);
+        const float ns = sqrtf(s0 * s0 + s1 * s1 + s2 * s2);
+        if (ns > 0.f) {                                            // torch: the 2-norm has zero subgradient at 0
+            const float c = a.lam_scale / n_vis / ns;
+            a.dL_dlog_scaling[3 * i] += c * s0 * e0;
+            a.dL_dlog_scaling[3 * i + 1] += c * s1 * e1;
+            a.dL_dlog_scaling[3 * i + 2] += c * s2 * e2;
+        }
+    }
+    if (a.max_radii2D && vis && !(a.guard && *a.guard)) {
+        a.max_radii2D[i] = fmaxf(a.max_radii2D[i], (float)a.radii[i]);
+        const float gx = a.dL_dmeans2D[3 * i], gy = a.dL_dmeans2D[3 * i + 1];
+        a.xyz_gradient_accum[i] += sqrtf(gx * gx + gy * gy);
+        a.denom[i] += 1.f;
+    }
+}
+
+}  // namespace
+
+extern "C" int ggs_registration_aux(int P, const float* xyz, const float* log_scaling, const int* radii,
+                                    const float* dL_dmeans2D, const float* opacity, const float* dL_dopacity,
+                                    float* dL_dopacity_logit, float threshold_xyz, float lambda_xyz,
+                                    float threshold_scale, float lambda_scale, float* dL_dxyz, float* dL_dlog_scaling,
+                                    float* max_radii2D, float* xyz_gradient_accum, float* denom, float* out_losses,
+                                    void* scratch, const void* guard, void* stream) {
+    ggs_clear_error_();
+    if (P <= 0) return GGS_OK;
+    if (!radii) return ggs_fail_(GGS_ERR_ARG, "ggs_registration_aux: radii is NULL");
+    const bool hinge = dL_dxyz || dL_dlog_scaling;
+    if (hinge && (!xyz || !log_scaling || !dL_dxyz || !dL_dlog_scaling || !scratch))
+        return ggs_fail_(GGS_ERR_ARG, "ggs_registration_aux: the hinge terms need xyz, log_scaling, both gradient buffers and scratch");
+    if (max_radii2D && (!xyz_gradient_accum || !denom || !dL_dmeans2D))
+        return ggs_fail_(GGS_ERR_ARG, "ggs_registration_aux: the statistics need xyz_gradient_accum, denom and dL_dmeans2D");
+    if (dL_dopacity_logit && (!opacity || !dL_dopacity))
+        return ggs_fail_(GGS_ERR_ARG, "ggs_registration_aux: the opacity chain rule needs opacity and dL_dopacity");
+    hipStream_t s = (hipStream_t)stream;
+    RegArgs a;
+    a.P = P; a.xyz = xyz; a.log_scaling = log_scaling; a.radii = radii; a.dL_dmeans2D = dL_dmeans2D;
+    a.opacity = opacity; a.dL_dopacity = dL_dopacity; a.dL_dopacity_logit = dL_dopacity_logit;
+    a.thr_xyz = threshold_xyz; a.lam_xyz = lambda_xyz; a.thr_scale = threshold_scale; a.lam_scale = lambda_scale;
+    a.dL_dxyz = dL_dxyz; a.dL_dlog_scaling = dL_dlog_scaling;
+    a.max_radii2D = max_radii2D; a.xyz_gradient_accum = xyz_gradient_accum; a.denom = denom;
+    a.out_losses = out_losses; a.sums = hinge ? static_cast<float*>(scratch) : nullptr;
+    a.guard = static_cast<const unsigned long long*>(guard);
+    const dim3 grid((unsigned)((P + 255) / 256));
+    if (hinge) {
+        if (ggs_zero_async(scratch, 16, s) != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "ggs_registration_aux: clearing the sums failed");
+        hipLaunchKernelGGL(k_reg_reduce, grid, dim3(256), 0, s, a);
+    }
+    hipLaunchKernelGGL(k_reg_apply, grid, dim3(256), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "registration_aux launch failed: %s", hipGetErrorString(e));
+    return GGS_OK;
+}

@@ -117,11 +117,17 @@ class GraphedRegistrationStep:
     replays the step -- so results never depend on the capacity guess.
 
     gaussians.optimizer must be a GraphAdam (ggsplat.adam).  Camera objects need world_view_transform,
-    full_proj_transform, camera_center, FoVx, FoVy (scene/cameras.py attributes)."""
+    full_proj_transform, camera_center, FoVx, FoVy (scene/cameras.py attributes).
+
+    lean=True (default) assembles the iteration directly from the C entry points -- mesh binding, rasterizer
+    forward/backward, fused photometric loss, ggs_registration_aux (hinges, opacity chain rule, densification
+    statistics), guarded Adam: ~30 kernels per iteration, no autograd, loss values returned as Python floats read back
+    with the overflow flag.  lean=False captures registration_step() itself (autograd + ~120 small PyTorch kernels);
+    both are tested against the eager step."""
 
     def __init__(self, gaussians, W: int, H: int, bg, opt=DEFAULT_OPT, pipe=DEFAULT_PIPE,
                  first_frame_template: bool = True, track_densification: bool = True, use_mask: bool = True,
-                 capacity_slack: float = 1.0):
+                 capacity_slack: float = 1.0, lean: bool = True):
         if not isinstance(gaussians.optimizer, GraphAdam):
             raise TypeError("GraphedRegistrationStep needs gaussians.optimizer to be a ggsplat.adam.GraphAdam")
         dev = gaussians._xyz.device
@@ -135,6 +141,12 @@ class GraphedRegistrationStep:
         self.mask = torch.ones(1, H, W, device=dev) if use_mask else None
         self._tan_host = torch.zeros(1, 2).pin_memory()
         self._hdr_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+        self.lean = bool(lean)
+        lam = float(opt.lambda_dssim)
+        self._w = torch.tensor([[1.0 - lam, -lam]], device=dev)          # d loss / d {mean|x-y|, mean ssim}
+        self._stats = torch.zeros(8, device=dev)                          # {sum|x-y|, sum ssim, loss_xyz, loss_scale, n_vis}
+        self._stats_host = torch.zeros(8).pin_memory()
+        self._aux_scratch = torch.zeros(4, device=dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out: Dict[str, torch.Tensor] = {}
         self.recaptures = 0
@@ -152,7 +164,75 @@ class GraphedRegistrationStep:
         if self.mask is not None and mask is not None:
             self.mask.copy_(mask.reshape(self.mask.shape), non_blocking=True)
 
+    def _body_lean(self, optimizer_step: bool, track: bool):
+        """registration_step() without autograd: the same kernels in the same order, called through the C ABI."""
+        import ctypes as C
+        from ._lib import check, lib, ptr
+        g, opt, cam = self.g, self.opt, self.cam
+        L = lib()
+        dev = g._xyz.device
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        H, W = cam.image_height, cam.image_width
+        P, Fn = g._xyz.shape[0], g.mesh.f.shape[0]
+        with torch.no_grad():
+            verts, faces, binding, bary = g.mesh.v, g.mesh.f, g.binding, g.gs_bc
+            xyz, scaling, rot = torch.empty_like(g._xyz), torch.empty_like(g._scaling), torch.empty_like(g._rotation)
+            check(L.ggs_mesh_bind_forward(P, Fn, ptr(verts), ptr(faces), ptr(binding), ptr(g._xyz), ptr(g._scaling),
+                                          ptr(g._rotation), ptr(bary), ptr(xyz), ptr(scaling), ptr(rot), stream),
+                  "ggs_mesh_bind_forward")
+            opacity = torch.sigmoid(g._opacity)
+            K = 1 + g._features_rest.shape[1]
+            shs = g._features_dc if K == 1 else torch.cat((g._features_dc, g._features_rest), dim=1)
+            color, radii, _, _, st = R.forward_views(
+                xyz, opacity, shs, None, scaling, rot, None, view=cam.world_view_transform,
+                proj=cam.full_proj_transform, campos=cam.camera_center, tanfov=cam.tanfov, bg=self.bg, W=W, H=H,
+                sh_degree=g.active_sh_degree, debug=self.pipe.debug)
+            hdr = R.last_header()
+            m = self.mask if opt.only_foreground_loss else None
+            scratch = torch.empty(L.ggs_photometric_scratch_bytes(1, H, W), device=dev, dtype=torch.uint8)
+            check(L.ggs_photometric_forward(1, H, W, ptr(color), ptr(self.gt), ptr(m), ptr(self._stats[0:2]),
+                                            ptr(scratch), stream), "ggs_photometric_forward")
+            dimg = torch.empty_like(color)
+            check(L.ggs_photometric_backward(1, H, W, ptr(color), ptr(self.gt), ptr(m), ptr(scratch), ptr(self._w),
+                                             ptr(dimg), stream), "ggs_photometric_backward")
+            gr = R.backward_views(st, dimg, want_means2D=True)
+            d_verts = torch.zeros_like(verts)
+            d_xyz, d_ls, d_rr = torch.empty_like(g._xyz), torch.empty_like(g._scaling), torch.empty_like(g._rotation)
+            check(L.ggs_mesh_bind_backward(P, Fn, ptr(verts), ptr(faces), ptr(binding), ptr(g._xyz), ptr(g._scaling),
+                                           ptr(g._rotation), ptr(bary), ptr(gr["means3D"]), ptr(gr["scales"]),
+                                           ptr(gr["rotations"]), ptr(d_verts), ptr(d_xyz), ptr(d_ls), ptr(d_rr), stream),
+                  "ggs_mesh_bind_backward")
+            d_op = torch.empty_like(g._opacity)
+            stats = self.fft and track
+            check(L.ggs_registration_aux(
+                P, ptr(g._xyz), ptr(g._scaling), ptr(radii), ptr(gr["means2D"]), ptr(opacity), ptr(gr["opacities"]),
+                ptr(d_op), float(opt.threshold_xyz), float(opt.lambda_xyz), float(opt.threshold_scale),
+                float(opt.lambda_scale), ptr(d_xyz) if self.fft else None, ptr(d_ls) if self.fft else None,
+                ptr(g.max_radii2D) if stats else None, ptr(g.xyz_gradient_accum) if stats else None,
+                ptr(g.denom) if stats else None, ptr(self._stats[2:5]), ptr(self._aux_scratch), ptr(hdr[1:2]), stream),
+                "ggs_registration_aux")
+            if optimizer_step and g.optimizer is not None:
+                g.mesh.v.grad, g._xyz.grad, g._scaling.grad, g._rotation.grad, g._opacity.grad = d_verts, d_xyz, d_ls, d_rr, d_op
+                gs = gr["shs"]
+                g._features_dc.grad = gs if K == 1 else gs[:, :1].contiguous()
+                g._features_rest.grad = torch.empty_like(g._features_rest) if K == 1 else gs[:, 1:].contiguous()
+                g.optimizer.step(guard=hdr[1:2])
+                g.optimizer.zero_grad()
+        return {}
+
+    def _losses_from_stats(self) -> Dict[str, float]:
+        s, opt = self._stats_host, self.opt
+        n = 3.0 * self.cam.image_height * self.cam.image_width
+        lam = float(opt.lambda_dssim)
+        d = {"img": float(s[0]) / n * (1.0 - lam), "ssim": 1.0 - float(s[1]) / n * lam}
+        if self.fft:
+            d["xyz"], d["scale"], d["n_visible"] = float(s[2]), float(s[3]), float(s[4])
+        d["loss"] = sum(v for k, v in d.items() if k != "n_visible")
+        return d
+
     def _body(self, optimizer_step: bool, track: bool):
+        if self.lean:
+            return self._body_lean(optimizer_step, track)
         d = registration_step(self.g, self.cam, self.gt, self.mask, self.bg, self.opt, self.pipe,
                               first_frame_template=self.fft, track_densification=track,
                               optimizer_step=optimizer_step, fused_loss=True)
@@ -179,7 +259,8 @@ class GraphedRegistrationStep:
         self.out = {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
 
     def __call__(self, cam, gt_image, mask=None) -> Dict[str, torch.Tensor]:
-        """One optimisation step.  Returns device scalars {"loss", "img", "ssim", ...} (overwritten by the next call)."""
+        """One optimisation step.  Returns {"loss", "img", "ssim", ...}: Python floats (lean) or device scalars that the
+        next call overwrites (lean=False)."""
         self._load(cam, gt_image, mask)
         if self.graph is None:
             self._capture()
@@ -187,9 +268,11 @@ class GraphedRegistrationStep:
         while True:
             self.graph.replay()
             self._hdr_host.copy_(self._hdr_dev, non_blocking=True)
+            if self.lean:
+                self._stats_host.copy_(self._stats, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             if int(self._hdr_host[1]) == 0:
-                return self.out
+                return self._losses_from_stats() if self.lean else self.out
             # the static binning capacity was too small for this view: nothing was updated (guarded kernels)
             R.grow_capacity(2.0)
             self.recaptures += 1

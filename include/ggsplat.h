@@ -220,6 +220,23 @@ int ggs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, flo
                   double beta1, double beta2, double eps, const void* state, const void* guard, void* stream);
 
 /*
+ * The rest of one s2 registration iteration in two kernels: hinge regularisers of the first-frame
+ * template with their gradients (s2_registration.py:262-265), sigmoid chain rule of the opacity
+ * (scene/gaussian_model.py:107-108) and the densification statistics (s2_registration.py:301-303,
+ * scene/gaussian_model.py:410-412).  vis_i = radii[i] > 0, means over the visible Gaussians.
+ *   xyz, log_scaling [P][3]: the LOCAL parameters _xyz / _scaling;  dL_dmeans2D [P][3] from ggs_backward.
+ *   dL_dxyz / dL_dlog_scaling [P][3]: gradient buffers the hinge gradients are ADDED to (both NULL: no hinge terms).
+ *   dL_dopacity_logit [P] (NULL: skip) = dL_dopacity * opacity (1 - opacity).
+ *   max_radii2D, xyz_gradient_accum, denom [P] (max_radii2D NULL: no statistics; left untouched when *guard != 0).
+ *   out_losses [3] = {loss_xyz, loss_scale, n_visible} (may be NULL);  scratch: 16 bytes, 16-byte aligned.
+ */
+int ggs_registration_aux(int P, const float* xyz, const float* log_scaling, const int* radii, const float* dL_dmeans2D,
+                         const float* opacity, const float* dL_dopacity, float* dL_dopacity_logit, float threshold_xyz,
+                         float lambda_xyz, float threshold_scale, float lambda_scale, float* dL_dxyz,
+                         float* dL_dlog_scaling, float* max_radii2D, float* xyz_gradient_accum, float* denom,
+                         float* out_losses, void* scratch, const void* guard, void* stream);
+
+/*
  * Visibility of mesh-bound Gaussians from one camera -- replaces the per-iteration open3d / Embree
  * ray cast of AvatarGaussianModel.get_visible_mask (scene/avatar_gaussian_model.py:227-263): ray i goes from
  * `cam` [3] (device) to targets[i] (the Gaussian's anchor on its face); mask[i] = 1 iff the FIRST triangle the
