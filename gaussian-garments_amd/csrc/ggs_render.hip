@@ -77,6 +77,20 @@ __device__ __forceinline__ float fold_rows(float q1, float q2, float r5) {
     return q1;
 }
 
+// Lane selects driven by explicit 64-bit lane masks.  The forward keeps its predicates (alpha test, stop, blend) as
+// SGPR masks so that their population counts run on the scalar unit; going through `bool` the compiler rebuilds a
+// mask from a 0/1 VGPR (v_cndmask + v_cmp) every time a ballot of a combined predicate is needed.
+__device__ __forceinline__ float sel_or_zero(uint64_t m, float a) {            // m ? a : 0
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(m));
+    return r;
+}
+__device__ __forceinline__ float sel(uint64_t m, float a, float b) {           // m ? a : b
+    float r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+
 __device__ __forceinline__ float bcast(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -152,16 +166,16 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
     __shared__ float4 s_rec[64 * 3];
     __shared__ uint32_t s_w[64];
     RoundLds lds{s_rec, s_w};
+    // pixels of this wave still compositing: a wave-uniform counter kept on the scalar unit (s_bcnt1 of the stop
+    // mask), so the walk ends at the very splat that finishes the tile without any per-splat VALU test
+    const float inf_v = __builtin_inff();
+    int rem[NQ], remaining = 0;     // per quadrant too: a finished quadrant is skipped by the same scalar branch as a masked one
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) { rem[q] = (int)__popcll(__builtin_amdgcn_ballot_w64(inside[q])); remaining += rem[q]; }
     if (L > 0) {
         Rec3 nxt = gather_round(rec, ids, 0, L, lane);
-        auto all_done = [&]() {
-            bool d = true;
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) d = d && (pxf[q] == __builtin_inff());
-            return __builtin_amdgcn_ballot_w64(!d) == 0;
-        };
         for (int first = 0; first < L; first += 64) {
-            if (all_done()) break;
+            if (remaining == 0) break;
             const Rec3 cur = nxt;
             if (first + 64 < L) nxt = gather_round(rec, ids, first + 64, L, lane);
             const int n = min(64, L - first);
@@ -179,27 +193,31 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
                 asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + j + 1));
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    if (!(word & (1u << (GGS_ID_BITS + q0 + q)))) continue;   // wave-uniform: one scalar branch
+                    if (!(word & (1u << (GGS_ID_BITS + q0 + q))) || rem[q] == 0) continue;   // wave-uniform: scalar branch
                     // predicated, branch-free per-pixel update: lane masks instead of nested exec juggling
                     const float dx = gx - pxf[q], dy = gy - pyf[q];
                     const float power = fmaf(cxx * dx, dx, fmaf(cyy * dy, dy, (cxy * dx) * dy));   // log2 of the falloff
                     const float alpha = __builtin_fminf(GGS_ALPHA_MAX, op * __builtin_amdgcn_exp2f(power));
-                    const bool ok = (power <= 0.f) & (alpha >= GGS_ALPHA_MIN);
-                    if (__builtin_amdgcn_ballot_w64(ok) == 0) continue;
+                    const uint64_t m_ok = __builtin_amdgcn_ballot_w64(power <= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= GGS_ALPHA_MIN);
+                    if (m_ok == 0) continue;
                     const float wa = alpha * T[q];
                     const float test_T = T[q] - wa;           // = T (1 - alpha)
-                    const bool stop = ok & (test_T < GGS_T_MIN);
-                    const bool app = ok & !stop;
-                    pxf[q] = stop ? __builtin_inff() : pxf[q];
-                    const float w = app ? wa : 0.f;
+                    const uint64_t m_stop = m_ok & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
+                    const uint64_t m_app = m_ok & ~m_stop;
+                    const int n_stop = (int)__popcll(m_stop);
+                    rem[q] -= n_stop; remaining -= n_stop;
+                    pxf[q] = sel(m_stop, inf_v, pxf[q]);
+                    const float w = sel_or_zero(m_app, wa);
                     C0[q] = fmaf(cr, w, C0[q]);
                     C1[q] = fmaf(cg, w, C1[q]);
                     C2[q] = fmaf(cb, w, C2[q]);
                     D[q] = fmaf(dep, w, D[q]);
                     A[q] += w;
                     T[q] -= w;
-                    last[q] = app ? posv : last[q];
-                    if (__builtin_amdgcn_ballot_w64(w > 0.f) != 0) blended |= 1u << (GGS_ID_BITS + q0 + q);   // w > 0 <=> app
+                    last[q] = __float_as_uint(sel(m_app, __uint_as_float(posv), __uint_as_float(last[q])));
+                    // some pixel of the quadrant passed the alpha test: keep the quadrant in the backward's mask (a
+                    // superset of "some pixel blended it" -- the backward re-tests every pixel -- at no VALU cost)
+                    blended |= 1u << (GGS_ID_BITS + q0 + q);
                 }
                 if (NQ == 4) {
                     if (lane == j) neww |= blended;
@@ -208,7 +226,7 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
                     const uint32_t mine = 1u << (GGS_ID_BITS + q0);
                     if ((word & mine) && !blended && lane == 0) atomicAnd(&ids[first + j], ~mine);
                 }
-                if ((j & 15) == 15 && all_done()) break;
+                if (remaining == 0) break;
             }
             if (NQ == 4 && lane < n) ids[first + lane] = neww;
         }
