@@ -4,7 +4,7 @@
 //   geom : SplatRec rec[V][P]            48 B per (view, Gaussian), AoS so that the
 //                                        render kernels gather one record = 3 x 16 B
 //                                        from one or two cache lines;
-//          SplatAux aux[V][P]            8 B: radius + SH clamp bits (binning / backward only).
+//          SplatAux aux[V][P]           16 B: radius + SH clamp bits + reachable-tile bitmask (binning / backward only).
 //   bin  : BinHeader | tile_count[V][T] | tile_cursor[V][T] | tile_offset[V][T] |
 //          view_base[V] | order[V*T] (work items v*T+t, heaviest tile lists first) |
 //          keys[cap] (u64: depth bits << 32 | quadrant mask << 28 | Gaussian id) | ids[cap] (u32:
@@ -61,8 +61,11 @@ static_assert(sizeof(SplatRec) == 48, "SplatRec must be 48 bytes");
 struct SplatAux {
     int radius;                  // 3-sigma radius in px (the `radii` output); 0 = culled
     unsigned clamped;            // bit c set: SH colour channel c was clamped at 0
+    unsigned long long tile_bits;  // bit (ry * rect_w + rx): tile (x0 + rx, y0 + ry) of the culled rect is reachable;
+                                   // valid when the rect has <= 64 tiles (GGS_TILE_BITS_MAX), else recomputed
 };
-static_assert(sizeof(SplatAux) == 8, "SplatAux must be 8 bytes");
+static_assert(sizeof(SplatAux) == 16, "SplatAux must be 16 bytes");
+#define GGS_TILE_BITS_MAX 64
 
 struct GradRec {                 // per-(view, Gaussian) accumulators over the pixels that blended the splat,
                                  // with t = G dL/dalpha and d = mean - pixel:

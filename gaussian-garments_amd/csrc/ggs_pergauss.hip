@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
     }
     if (live) {
         a.radii[vg] = radius;
-        SplatAux ax; ax.radius = radius; ax.clamped = clamped;
+        SplatAux ax; ax.radius = radius; ax.clamped = clamped; ax.tile_bits = 0;
         a.aux[vg] = ax;
         float4* dst = reinterpret_cast<float4*>(rec);
         const float4* src = reinterpret_cast<const float4*>(&out);
@@ -159,14 +159,21 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
     const Footprint fp = ggs_footprint(out.px, out.py, out.cx, out.cy, out.cz, out.opacity);
     uint32_t* cnt = a.tile_count + (size_t)v * a.T;
     const TileWindow w = block_tile_window(s_box, has, x0, y0, x1, y1);
+    // The exact ellipse-vs-tile test runs ONCE per (splat, tile): its outcome is kept as a bitmask over the culled
+    // rect (row-major, <= 64 tiles) in SplatAux so the scatter kernel's two passes only test a bit.
+    unsigned long long bits = 0;
+    unsigned idx = 0;
     if (w.dense) {
         const int area = w.w * w.h;
         for (int i = threadIdx.x; i < area; i += 256) s_cnt[i] = 0;
         __syncthreads();
         if (has)
             for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x)
-                    if (ggs_tile_reachable(fp, x, y)) atomicAdd(&s_cnt[(y - w.y0) * w.w + (x - w.x0)], 1u);
+                for (int x = x0; x < x1; ++x, ++idx)
+                    if (ggs_tile_reachable(fp, x, y)) {
+                        atomicAdd(&s_cnt[(y - w.y0) * w.w + (x - w.x0)], 1u);
+                        if (idx < GGS_TILE_BITS_MAX) bits |= 1ull << idx;
+                    }
         __syncthreads();
         for (int i = threadIdx.x; i < area; i += 256) {
             const uint32_t c = s_cnt[i];
@@ -174,9 +181,13 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
         }
     } else if (has) {
         for (int y = y0; y < y1; ++y)
-            for (int x = x0; x < x1; ++x)
-                if (ggs_tile_reachable(fp, x, y)) atomicAdd(&cnt[y * gx + x], 1u);
+            for (int x = x0; x < x1; ++x, ++idx)
+                if (ggs_tile_reachable(fp, x, y)) {
+                    atomicAdd(&cnt[y * gx + x], 1u);
+                    if (idx < GGS_TILE_BITS_MAX) bits |= 1ull << idx;
+                }
     }
+    if (has) a.aux[vg].tile_bits = bits;
 }
 
 // K3: grid (ceil(P/256), V).  For every (splat, tile) instance take a slot in the tile's
@@ -194,8 +205,11 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
     unsigned bbx = 1u, bby = 1u;
     Footprint fp = {0.f, 0.f, 1.f, 0.f, 1.f, -1.f, 0.f, 0.f};
     bool has = false;
+    unsigned long long bits = 0;
     if (g < a.P) {
-        const int radius = a.aux[(size_t)v * a.P + g].radius;
+        const SplatAux ax = a.aux[(size_t)v * a.P + g];
+        const int radius = ax.radius;
+        bits = ax.tile_bits;
         if (radius > 0) {
             const SplatRec* rec = a.rec + (size_t)v * a.P + g;
             const float4 r0 = reinterpret_cast<const float4*>(rec)[0];
@@ -213,6 +227,10 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
     const uint32_t* off = a.tile_offset + (size_t)v * a.T;
     unsigned long long* keys = a.keys + a.view_base[v];
     const TileWindow w = block_tile_window(s_box, has, x0, y0, x1, y1);
+    // membership of tile (x, y) = bit of the mask the preprocess pass stored (rects of <= 64 tiles), else re-tested
+    const bool small = (x1 - x0) * (y1 - y0) <= GGS_TILE_BITS_MAX;
+    auto member = [&](unsigned idx, int x, int y) { return small ? ((bits >> idx) & 1ull) != 0 : ggs_tile_reachable(fp, x, y); };
+    unsigned idx = 0;
     if (w.dense) {
         // count in LDS -> one returning global atomic per touched tile claims the workgroup's run of
         // slots -> second LDS pass hands out the slots inside the run
@@ -221,8 +239,8 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
         __syncthreads();
         if (has)
             for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x)
-                    if (ggs_tile_reachable(fp, x, y)) atomicAdd(&s_cnt[(y - w.y0) * w.w + (x - w.x0)], 1u);
+                for (int x = x0; x < x1; ++x, ++idx)
+                    if (member(idx, x, y)) atomicAdd(&s_cnt[(y - w.y0) * w.w + (x - w.x0)], 1u);
         __syncthreads();
         for (int i = threadIdx.x; i < area; i += 256) {
             const uint32_t c = s_cnt[i];
@@ -233,18 +251,19 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
             }
         }
         __syncthreads();
+        idx = 0;
         if (has)
             for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x) {
-                    if (!ggs_tile_reachable(fp, x, y)) continue;
+                for (int x = x0; x < x1; ++x, ++idx) {
+                    if (!member(idx, x, y)) continue;
                     const unsigned long long qm = ggs_quad_mask(fp, bbx, bby, x, y);
                     const int i = (y - w.y0) * w.w + (x - w.x0);
                     keys[(size_t)s_base[i] + atomicAdd(&s_cnt[i], 1u)] = key | qm;
                 }
     } else if (has) {
         for (int y = y0; y < y1; ++y)
-            for (int x = x0; x < x1; ++x) {
-                if (!ggs_tile_reachable(fp, x, y)) continue;
+            for (int x = x0; x < x1; ++x, ++idx) {
+                if (!member(idx, x, y)) continue;
                 const unsigned long long qm = ggs_quad_mask(fp, bbx, bby, x, y);
                 const int t = y * a.gx + x;
                 const uint32_t slot = atomicAdd(&cur[t], 1u);
