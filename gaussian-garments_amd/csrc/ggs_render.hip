@@ -250,11 +250,116 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
     }
 }
 
+
+// K4b body, latency mapping (one wave per (tile, quadrant), launches too small to fill the chip).  A wave that has
+// its SIMD almost to itself spends most of each splat waiting: LDS record read -> 9 dependent VALU ops of the alpha
+// test -> blend.  Two consecutive splats are therefore tested together (independent chains, both records read up
+// front) and blended one after the other; the arithmetic per pixel is the same as in render_fwd_body.
+__device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
+    if (a.header->overflow) return;
+    const uint32_t item = a.order[blockIdx.x >> 2];
+    const int q0 = (int)(blockIdx.x & 3);
+    const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
+    const int tx = t % a.gx, ty = t / a.gx;
+    const int px = tx * GGS_TILE + (lane & 7) + (q0 & 1) * 8, py = ty * GGS_TILE + (lane >> 3) + (q0 >> 1) * 8;
+    const int L = (int)a.tile_count[(size_t)v * a.T + t];
+    const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
+    uint32_t* ids = a.ids + base;
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
+    const float inf_v = __builtin_inff();
+    const bool inside = px < a.W && py < a.H;
+    float pxf = inside ? (float)px : inf_v;
+    const float pyf = (float)py;
+    float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
+    uint32_t last = 0;
+    int remaining = (int)__popcll(__builtin_amdgcn_ballot_w64(inside));
+    const uint32_t mine = 1u << (GGS_ID_BITS + q0);
+
+    __shared__ float4 s_rec[64 * 3];
+    __shared__ uint32_t s_w[64];
+    RoundLds lds{s_rec, s_w};
+    if (L > 0) {
+        Rec3 nxt = gather_round(rec, ids, 0, L, lane);
+        for (int first = 0; first < L && remaining != 0; first += 64) {
+            const Rec3 cur = nxt;
+            if (first + 64 < L) nxt = gather_round(rec, ids, first + 64, L, lane);
+            const int n = min(64, L - first);
+            lds.put(cur, lane);
+            for (int j = 0; j < n && remaining != 0; j += 2) {
+                const int jb = j + 1 < n ? j + 1 : j;
+                const uint32_t wA = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[j]);
+                const uint32_t wB = j + 1 < n ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[jb]) : 0u;
+                const bool useA = (wA & mine) != 0, useB = (wB & mine) != 0;
+                if (!useA && !useB) continue;
+                const float4 a0 = s_rec[j * 3 + 0], a1 = s_rec[j * 3 + 1], a2 = s_rec[j * 3 + 2];
+                const float4 b0 = s_rec[jb * 3 + 0], b1 = s_rec[jb * 3 + 1], b2 = s_rec[jb * 3 + 2];
+                // both alpha tests (independent of T and of each other)
+                const float dxA = a0.x - pxf, dyA = a0.y - pyf, dxB = b0.x - pxf, dyB = b0.y - pyf;
+                const float pA = fmaf(a0.z * dxA, dxA, fmaf(a1.x * dyA, dyA, (a0.w * dxA) * dyA));
+                const float pB = fmaf(b0.z * dxB, dxB, fmaf(b1.x * dyB, dyB, (b0.w * dxB) * dyB));
+                const float alA = __builtin_fminf(GGS_ALPHA_MAX, a1.y * __builtin_amdgcn_exp2f(pA));
+                const float alB = __builtin_fminf(GGS_ALPHA_MAX, b1.y * __builtin_amdgcn_exp2f(pB));
+                uint64_t okA = __builtin_amdgcn_ballot_w64(pA <= 0.f) & __builtin_amdgcn_ballot_w64(alA >= GGS_ALPHA_MIN);
+                uint64_t okB = __builtin_amdgcn_ballot_w64(pB <= 0.f) & __builtin_amdgcn_ballot_w64(alB >= GGS_ALPHA_MIN);
+                if (!useA) okA = 0;
+                if (!useB) okB = 0;
+                uint64_t stopA = 0;
+                if (okA) {
+                    const float wa = alA * T;
+                    const float test_T = T - wa;
+                    stopA = okA & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
+                    const uint64_t app = okA & ~stopA;
+                    remaining -= (int)__popcll(stopA);
+                    pxf = sel(stopA, inf_v, pxf);
+                    const float w = sel_or_zero(app, wa);
+                    C0 = fmaf(a1.z, w, C0); C1 = fmaf(a1.w, w, C1); C2 = fmaf(a2.x, w, C2); D = fmaf(a2.y, w, D);
+                    A += w; T -= w;
+                    uint32_t posv;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + j + 1));
+                    last = __float_as_uint(sel(app, __uint_as_float(posv), __uint_as_float(last)));
+                } else if (useA && lane == 0) {
+                    atomicAnd(&ids[first + j], ~mine);          // four waves share the word: clear only this quadrant's bit
+                }
+                okB &= ~stopA;                                   // a pixel that stopped at A no longer takes B
+                if (remaining == 0) okB = 0;
+                if (okB) {
+                    const float wa = alB * T;
+                    const float test_T = T - wa;
+                    const uint64_t stop = okB & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
+                    const uint64_t app = okB & ~stop;
+                    remaining -= (int)__popcll(stop);
+                    pxf = sel(stop, inf_v, pxf);
+                    const float w = sel_or_zero(app, wa);
+                    C0 = fmaf(b1.z, w, C0); C1 = fmaf(b1.w, w, C1); C2 = fmaf(b2.x, w, C2); D = fmaf(b2.y, w, D);
+                    A += w; T -= w;
+                    uint32_t posv;
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + j + 2));
+                    last = __float_as_uint(sel(app, __uint_as_float(posv), __uint_as_float(last)));
+                } else if (useB && lane == 0) {
+                    atomicAnd(&ids[first + j + 1], ~mine);
+                }
+            }
+        }
+    }
+    if (!inside) return;
+    const size_t HW = (size_t)a.H * a.W;
+    const float* bg = a.bg + 3 * v;
+    float* oc = a.out_color + (size_t)v * 3 * HW;
+    const size_t pix = (size_t)py * a.W + px;
+    a.final_T[(size_t)v * HW + pix] = T;
+    a.n_contrib[(size_t)v * HW + pix] = last;
+    oc[pix] = fmaf(T, bg[0], C0);
+    oc[HW + pix] = fmaf(T, bg[1], C1);
+    oc[2 * HW + pix] = fmaf(T, bg[2], C2);
+    a.out_depth[(size_t)v * HW + pix] = D;
+    a.out_alpha[(size_t)v * HW + pix] = A;
+}
+
 }  // namespace
 
 // K4b: grid V*T work items (x4 for the per-quadrant variant), block 64.
 __global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) { render_fwd_body<4>(a); }
-__global__ __launch_bounds__(64) void ggs_k_render_fwd_quad(RenderArgs a) { render_fwd_body<1>(a); }
+__global__ __launch_bounds__(64) void ggs_k_render_fwd_quad(RenderArgs a) { render_fwd_quadwave(a); }
 
 namespace {
 
