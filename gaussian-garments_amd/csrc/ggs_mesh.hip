@@ -60,6 +60,16 @@ __device__ __forceinline__ void face_frame(const float* verts, const int64_t* fa
 }
 
 // Unnormalised quaternion (x,y,z,w) of a rotation matrix R[r][c]; `choice` = branch taken.
+// The diagonal branches are instantiated per index: with run-time indices the 3x3 / 4-vectors live in scratch
+// memory (120 B per thread) and the kernels, which are pure latency chains at 100k threads, run ~2x longer.
+template <int I>
+__device__ __forceinline__ void quat_diag_branch(const float R[3][3], float tr, float u[4]) {
+    constexpr int J = (I + 1) % 3, K = (J + 1) % 3;
+    u[I] = 1.f - tr + 2.f * R[I][I];
+    u[J] = R[J][I] + R[I][J];
+    u[K] = R[K][I] + R[I][K];
+    u[3] = R[K][J] - R[J][K];
+}
 __device__ __forceinline__ void rotmat_to_quat_raw(const float R[3][3], float u[4], int& choice) {
     const float tr = R[0][0] + R[1][1] + R[2][2];
     choice = 0;
@@ -69,13 +79,22 @@ __device__ __forceinline__ void rotmat_to_quat_raw(const float R[3][3], float u[
     if (tr > best) { choice = 3; }
     if (choice == 3) {
         u[0] = R[2][1] - R[1][2]; u[1] = R[0][2] - R[2][0]; u[2] = R[1][0] - R[0][1]; u[3] = 1.f + tr;
+    } else if (choice == 0) {
+        quat_diag_branch<0>(R, tr, u);
+    } else if (choice == 1) {
+        quat_diag_branch<1>(R, tr, u);
     } else {
-        const int i = choice, j = (i + 1) % 3, k = (j + 1) % 3;
-        u[i] = 1.f - tr + 2.f * R[i][i];
-        u[j] = R[j][i] + R[i][j];
-        u[k] = R[k][i] + R[i][k];
-        u[3] = R[k][j] - R[j][k];
+        quat_diag_branch<2>(R, tr, u);
     }
+}
+template <int CI>
+__device__ __forceinline__ void quat_diag_branch_vjp(const float du[4], float dR[3][3]) {
+    constexpr int CJ = (CI + 1) % 3, CK = (CJ + 1) % 3;
+    dR[0][0] -= du[CI]; dR[1][1] -= du[CI]; dR[2][2] -= du[CI];
+    dR[CI][CI] += 2.f * du[CI];
+    dR[CJ][CI] += du[CJ]; dR[CI][CJ] += du[CJ];
+    dR[CK][CI] += du[CK]; dR[CI][CK] += du[CK];
+    dR[CK][CJ] += du[3]; dR[CJ][CK] -= du[3];
 }
 
 // Hamilton product of (w,x,y,z) quaternions.
@@ -194,13 +213,12 @@ __global__ __launch_bounds__(256) void k_mesh_bwd(MeshArgs a) {
         dR[0][2] += du[1]; dR[2][0] -= du[1];
         dR[1][0] += du[2]; dR[0][1] -= du[2];
         dR[0][0] += du[3]; dR[1][1] += du[3]; dR[2][2] += du[3];
+    } else if (Q.choice == 0) {
+        quat_diag_branch_vjp<0>(du, dR);
+    } else if (Q.choice == 1) {
+        quat_diag_branch_vjp<1>(du, dR);
     } else {
-        const int ci = Q.choice, cj = (ci + 1) % 3, ck = (cj + 1) % 3;
-        dR[0][0] -= du[ci]; dR[1][1] -= du[ci]; dR[2][2] -= du[ci];
-        dR[ci][ci] += 2.f * du[ci];
-        dR[cj][ci] += du[cj]; dR[ci][cj] += du[cj];
-        dR[ck][ci] += du[ck]; dR[ci][ck] += du[ck];
-        dR[ck][cj] += du[3]; dR[cj][ck] -= du[3];
+        quat_diag_branch_vjp<2>(du, dR);
     }
     V3 da0 = {dR[0][0], dR[1][0], dR[2][0]};
     V3 da1 = {dR[0][1], dR[1][1], dR[2][1]};

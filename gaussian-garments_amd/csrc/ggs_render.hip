@@ -15,9 +15,10 @@
 //     folds the 9-10 values into ONE register (each total in its own lane), and a single vector
 //     float-atomic instruction adds them to the splat's GradRec.
 //
-// Roofline: HBM nominally (algorithmic bytes: forward N*48 B gathers + 28 B/pixel outputs;
-// backward N*48 + 20 B/pixel + N*36 B of atomics), VALU/exp bound in practice:
-// ~4*(15 test + 8 blend) VALU per (tile, splat) forward, ~4*(15 + 45) + 54 backward.
+// Roofline: HBM nominally (algorithmic bytes: forward N*48 B gathers + 28 B/pixel outputs; backward N*48 +
+// 20 B/pixel + N*36 B of atomics); measured: bound by VALU instruction issue (SQ counters, profiles/r01_sq_counters.md:
+// INSTS_VALU x 4 cycles fills 96-100 % of the kernel time).  Per (tile, splat): ~10 VALU of overhead + per active
+// quadrant 11 (alpha test) + 12 (blend) forward; ~13 + 21 (reduction) + 35 per quadrant backward.
 #include "ggs_kernels.h"
 
 namespace {
@@ -91,14 +92,6 @@ __device__ __forceinline__ float sel(uint64_t m, float a, float b) {           /
     return r;
 }
 
-__device__ __forceinline__ float bcast(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-__device__ __forceinline__ unsigned bcast_u(float v, int lane) {
-    return (unsigned)__builtin_amdgcn_readlane(__float_as_int(v), lane);
-}
-
 struct Rec3 { float4 a, b, c; uint32_t w; };   // record of splat (first + lane) and its id word
 
 __device__ __forceinline__ Rec3 gather_round(const float4* __restrict__ rec, const uint32_t* __restrict__ ids,
@@ -132,9 +125,10 @@ struct RoundLds {
 namespace {
 
 // K4b body.  NQ = 4: one wave per tile, lane = 4 pixels (one per quadrant) -- the throughput mapping.
-// NQ = 1: one wave per (tile, quadrant), grid 4x larger -- the latency mapping for launches too small to fill
-// the chip (a single view has ~1.2k non-empty tiles for 1024 SIMDs and is bounded by the serial walk of its
-// longest tile; splitting the tile over 4 waves shortens that chain ~3x).  Same arithmetic, same results.
+// (The latency mapping for launches too small to fill the chip -- one wave per (tile, quadrant), grid 4x larger:
+// a single view has ~1.1k non-empty tiles of ~300 splats for 1024 SIMDs and is bounded by the serial walk of its
+// longest tile -- is render_fwd_quadwave below; the backward keeps both mappings in one template.)
+// Same arithmetic per pixel, bit-identical results.
 template <int NQ>
 __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
     if (a.header->overflow) return;
