@@ -235,3 +235,25 @@ def test_multi_view_batch_matches_single_views():
                 acc[k] += g1[k]
     for k in acc:
         assert rel_l1(gb[k], acc[k]) <= 1e-5, k
+
+
+# (P, W, H, sh_degree, seed, scale_mul, opacity_boost, cam, bg): ragged image sizes (not multiples of the 16-px tile
+# or the 8-px quadrant), one / a handful of splats, splats spanning hundreds of tiles (rect > 64 tiles: the
+# reachable-tile bitmask is not used), near-opaque splats (0.99 clamp, early termination), non-zero backgrounds
+SWEEP = [
+    (1, 33, 17, 0, 5, 30.0, 4.0, 0, (0.2, 0.5, 0.9)),
+    (7, 77, 53, 1, 6, 12.0, 2.0, 1, (0.0, 0.0, 0.0)),
+    (300, 130, 95, 2, 7, 3.0, 0.0, 2, (1.0, 1.0, 1.0)),
+    (900, 208, 120, 3, 8, 6.0, 3.0, 3, (0.3, 0.1, 0.7)),
+    (2500, 161, 161, 0, 9, 1.5, 1.0, 1, (0.0, 0.0, 0.0)),
+    (64, 320, 200, 1, 10, 40.0, -1.0, 2, (0.5, 0.5, 0.5)),
+]
+
+
+@pytest.mark.parametrize("P,W,H,deg,seed,scale_mul,boost,cam_index,bg", SWEEP)
+def test_random_sweep(P, W, H, deg, seed, scale_mul, boost, cam_index, bg):
+    sc, cam = small_scene(P=P, W=W, H=H, sh_degree=deg, seed=seed, scale_mul=scale_mul, cam_index=cam_index,
+                          opacity_boost=boost)
+    _compare(_add_precomp(sc), cam, list(bg), dict(sh=True, cov=False))
+    if seed % 2 == 0:
+        _compare(sc, cam, list(bg), dict(sh=False, cov=True, da=False))
