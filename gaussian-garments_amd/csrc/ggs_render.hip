@@ -279,12 +279,16 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
             if (first + 64 < L) nxt = gather_round(rec, ids, first + 64, L, lane);
             const int n = min(64, L - first);
             lds.put(cur, lane);
-            for (int j = 0; j < n && remaining != 0; j += 2) {
-                const int jb = j + 1 < n ? j + 1 : j;
-                const uint32_t wA = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[j]);
-                const uint32_t wB = j + 1 < n ? (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[jb]) : 0u;
-                const bool useA = (wA & mine) != 0, useB = (wB & mine) != 0;
-                if (!useA && !useB) continue;
+            // entries of the round that reach this quadrant, as a lane mask: the walk takes them two at a time and
+            // never touches the others (about half of a tile's list)
+            uint64_t todo = __builtin_amdgcn_ballot_w64((cur.w & mine) != 0);
+            if (n < 64) todo &= (1ull << n) - 1ull;
+            while (todo != 0 && remaining != 0) {
+                const int j = __builtin_ctzll(todo);
+                todo &= todo - 1;
+                const bool useA = true, useB = todo != 0;
+                const int jb = useB ? __builtin_ctzll(todo) : j;
+                todo &= todo - 1;                                  // (0 & -1 = 0 when B does not exist)
                 const float4 a0 = s_rec[j * 3 + 0], a1 = s_rec[j * 3 + 1], a2 = s_rec[j * 3 + 2];
                 const float4 b0 = s_rec[jb * 3 + 0], b1 = s_rec[jb * 3 + 1], b2 = s_rec[jb * 3 + 2];
                 // both alpha tests (independent of T and of each other)
@@ -327,10 +331,10 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
                     C0 = fmaf(b1.z, w, C0); C1 = fmaf(b1.w, w, C1); C2 = fmaf(b2.x, w, C2); D = fmaf(b2.y, w, D);
                     A += w; T -= w;
                     uint32_t posv;
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + j + 2));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + jb + 1));
                     last = __float_as_uint(sel(app, __uint_as_float(posv), __uint_as_float(last)));
                 } else if (useB && lane == 0) {
-                    atomicAnd(&ids[first + j + 1], ~mine);
+                    atomicAnd(&ids[first + jb], ~mine);
                 }
             }
         }
@@ -433,10 +437,16 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
         const int first = r * 64;
         const int n = min(64, maxc - first);
         lds.put(cur, lane);
-        for (int j = n - 1; j >= 0; --j) {
+        // Entries of the round the forward blended somewhere in this wave's pixels, as a lane mask (lane i holds entry i):
+        // the walk jumps from set bit to set bit on the scalar unit, so an entry that is not ours (21 % of a tile's
+        // list, 63 % for a per-quadrant wave) costs nothing -- not even the LDS latency of reading its id word.
+        uint64_t todo = __builtin_amdgcn_ballot_w64((cur.w & my_bits) != 0);
+        if (n < 64) todo &= (1ull << n) - 1ull;
+        while (todo) {
+            const int j = 63 - __builtin_clzll(todo);
+            todo &= ~(1ull << j);
             const int pos = first + j;                  // list position; pixel q blended it iff pos < nc[q]
             const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[j]);
-            if (!(word & my_bits)) continue;            // the forward blended this splat nowhere in this wave's pixels
             const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1], rc = s_rec[j * 3 + 2];
             const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y;
             const float cr = rb.z, cg = rb.w, cb = rc.x, dep = rc.y;
