@@ -54,37 +54,41 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
 
 }  // namespace
 
-// Pass A: grid (ceil(W/32), ceil(H/32), V*3), block 256.
+// Pass A: grid (ceil(W/32), ceil(H/32), V), block 256.  A workgroup walks the three colour channels of its tile: the
+// mask and the index arithmetic are shared, and the global loads of channel c + 1 are in flight while channel c is
+// filtered (with 3 workgroups per CU -- LDS -- nothing else hides the HBM latency of the tile + halo reads).
 __global__ __launch_bounds__(256) void ggs_k_loss_stats(LossArgs a) {
     __shared__ float sx[LI][LI + 1], sy[LI][LI + 1];
     __shared__ float hh[5][LI][LT + 1];
     __shared__ float s_red[4];
     const int tid = threadIdx.x;
-    const int v = blockIdx.z / 3, ch = blockIdx.z % 3;
+    const int v = blockIdx.z;
     const int ox = blockIdx.x * LT, oy = blockIdx.y * LT;
     const size_t HW = (size_t)a.H * a.W;
-    const float* img = a.img + ((size_t)v * 3 + ch) * HW;
-    const float* gt = a.gt + ((size_t)v * 3 + ch) * HW;
     const float* mask = a.mask ? a.mask + (size_t)v * HW : nullptr;
 
-    // Tile + halo into LDS.  All global loads of a thread are issued before the first use (7 independent elements
-    // per thread, fully unrolled): with ~3 waves per SIMD the kernel is otherwise bound by 7 serial HBM round trips.
-    float l1 = 0.f;
+    constexpr int NL = (LI * LI + 255) / 256;
+    float xr[NL], yr[NL], mr[NL];
+    size_t pp[NL];
+    bool in[NL];
     {
-        constexpr int NL = (LI * LI + 255) / 256;
-        float xr[NL], yr[NL], mr[NL];
-        bool in[NL];
+        const float* img = a.img + (size_t)v * 3 * HW;
+        const float* gt = a.gt + (size_t)v * 3 * HW;
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             const int i = tid + j * 256;
             const int r = i / LI, c = i % LI;
             const int y = oy + r - LH, x = ox + c - LH;
             in[j] = i < LI * LI && x >= 0 && x < a.W && y >= 0 && y < a.H;
-            const size_t p = in[j] ? (size_t)y * a.W + x : 0;
-            xr[j] = in[j] ? img[p] : 0.f;
-            yr[j] = in[j] ? gt[p] : 0.f;
-            mr[j] = (in[j] && mask) ? mask[p] : 1.f;
+            pp[j] = in[j] ? (size_t)y * a.W + x : 0;
+            xr[j] = in[j] ? img[pp[j]] : 0.f;
+            yr[j] = in[j] ? gt[pp[j]] : 0.f;
+            mr[j] = (in[j] && mask) ? mask[pp[j]] : 1.f;
         }
+    }
+    float l1 = 0.f, ssum = 0.f;
+    for (int ch = 0; ch < 3; ++ch) {
+    {
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             const int i = tid + j * 256;
@@ -97,6 +101,15 @@ __global__ __launch_bounds__(256) void ggs_k_loss_stats(LossArgs a) {
         }
     }
     __syncthreads();
+    if (ch < 2) {                      // next channel's tile + halo: consumed after this channel's two filter passes
+        const float* img = a.img + ((size_t)v * 3 + ch + 1) * HW;
+        const float* gt = a.gt + ((size_t)v * 3 + ch + 1) * HW;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            xr[j] = in[j] ? img[pp[j]] : 0.f;
+            yr[j] = in[j] ? gt[pp[j]] : 0.f;
+        }
+    }
     // horizontal pass, register blocked: thread = (row, 8 adjacent output columns) reads its 18 inputs of x and y once
     // (36 LDS reads for 8 outputs x 5 maps instead of 176) -- the kernel is bound by LDS latency, not by the FMAs.
     // Accumulation order per output is unchanged (taps 0..10).
@@ -122,7 +135,6 @@ __global__ __launch_bounds__(256) void ggs_k_loss_stats(LossArgs a) {
     }
     __syncthreads();
     // vertical pass + SSIM map + derivative maps: thread = (column, 4 adjacent output rows), 14 reads per map
-    float ssum = 0.f;
     float* dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW;
     {
         const int c = tid & 31, r0 = (tid >> 5) * 4;
@@ -159,6 +171,8 @@ __global__ __launch_bounds__(256) void ggs_k_loss_stats(LossArgs a) {
             dm[2 * HW + p] = 2.f * A1 * inv;      // d/dE[xy]
         }
     }
+    __syncthreads();                   // hh and sx / sy are rewritten by the next channel
+    }  // ch
     l1 = block_sum(l1, s_red);
     ssum = block_sum(ssum, s_red);
     if (tid == 0) {
@@ -281,7 +295,7 @@ int ggs_photometric_forward(int n_views, int H, int W, const float* img, const f
     a.sums = sums;
     if (ggs_zero_async(sums, (size_t)n_views * 2 * sizeof(float), s) != hipSuccess)
         return ggs_fail_(GGS_ERR_HIP, "ggs_photometric_forward: clearing the sums failed");
-    const dim3 grid((unsigned)((W + LT - 1) / LT), (unsigned)((H + LT - 1) / LT), (unsigned)(n_views * 3));
+    const dim3 grid((unsigned)((W + LT - 1) / LT), (unsigned)((H + LT - 1) / LT), (unsigned)n_views);
     hipLaunchKernelGGL(ggs_k_loss_stats, grid, dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "loss_stats launch failed: %s", hipGetErrorString(e));
