@@ -275,8 +275,15 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
         a.tile_count = tile_count; a.tile_offset = tile_offset; a.view_base = view_base; a.keys = keys; a.ids = ids;
         prof_start(K_SORT, s);
         // persistent grids sized for the chip (256 CUs), not for the item count: most items are empty tiles
-        hipLaunchKernelGGL(ggs_k_sort_tiles, dim3((unsigned)(n_items < 1280 ? n_items : 1280)), dim3(256), 0, s, a);
-        hipLaunchKernelGGL(ggs_k_sort_tiles_wave, dim3((unsigned)((n_items + 3) / 4 < 2048 ? (n_items + 3) / 4 : 2048)), dim3(256), 0, s, a);
+        const unsigned n_block = (unsigned)(n_items < 1280 ? n_items : 1280);
+        const unsigned n_wave = (unsigned)((n_items + 3) / 4 < 2048 ? (n_items + 3) / 4 : 2048);
+        if (n_items < GGS_QUAD_ITEMS) {
+            // small launch (latency bound): both list classes in one grid so the two passes overlap
+            hipLaunchKernelGGL(ggs_k_sort_tiles, dim3(n_block + n_wave), dim3(256), 0, s, a, n_block);
+        } else {
+            hipLaunchKernelGGL(ggs_k_sort_tiles, dim3(n_block), dim3(256), 0, s, a, n_block);
+            hipLaunchKernelGGL(ggs_k_sort_tiles_wave, dim3(n_wave), dim3(256), 0, s, a);
+        }
         prof_stop(K_SORT, s);
         GGS_TRY(check("sort_tiles", s, p->debug));
     }

@@ -149,15 +149,14 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr key, int L, int n2, int tid)
 // wave-local -- no workgroup barrier at all, and every lane carries n2/128 independent
 // compare-exchanges per sub-step (ILP hides the LDS latency the 256-thread version exposed).
 #define GGS_SORT_WAVE_CAP 512
-__global__ __launch_bounds__(256) void ggs_k_sort_tiles_wave(SortArgs a) {
-    if (a.header->overflow) return;
-    __shared__ unsigned long long s_all[4][GGS_SORT_WAVE_CAP];
+namespace {
+__device__ __forceinline__ void sort_tiles_wave_body(const SortArgs& a, unsigned long long* s_mem, uint32_t bid, uint32_t nblk) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const NonEmptyItems it = ggs_nonempty_items(a.bucket_count, (uint32_t)a.n_items);
-    unsigned long long* key = s_all[wave];
+    unsigned long long* key = s_mem + wave * GGS_SORT_WAVE_CAP;
     // persistent waves over the non-empty work items only (the empty ~90 % of an image never cost a
     // workgroup launch); round-robin over a longest-first list keeps the waves evenly loaded
-    for (uint32_t r = blockIdx.x * 4 + wave; r < it.n; r += gridDim.x * 4) {
+    for (uint32_t r = bid * 4 + wave; r < it.n; r += nblk * 4) {
     const uint32_t item = a.order[(size_t)r * it.stride];
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T);
     const int L = (int)a.tile_count[(size_t)v * a.T + t];
@@ -196,12 +195,10 @@ __global__ __launch_bounds__(256) void ggs_k_sort_tiles_wave(SortArgs a) {
 // K4a-large: persistent grid over the work items with more than GGS_SORT_WAVE_CAP keys (first in order[]), block 256.
 // Sorts the tile's key segment by (depth bits, id) and
 // writes the id-word list (quadrant mask << 28 | id) the render kernels walk.
-__global__ __launch_bounds__(256) void ggs_k_sort_tiles(SortArgs a) {
-    if (a.header->overflow) return;
+__device__ __forceinline__ void sort_tiles_block_body(const SortArgs& a, unsigned long long* s_key, uint32_t bid, uint32_t nblk) {
     const int tid = threadIdx.x;
     const NonEmptyItems it = ggs_nonempty_items(a.bucket_count, (uint32_t)a.n_items);
-    __shared__ unsigned long long s_key[GGS_SORT_CAP];
-    for (uint32_t r = blockIdx.x; r < it.n_long; r += gridDim.x) {
+    for (uint32_t r = bid; r < it.n_long; r += nblk) {
     const uint32_t item = a.order[(size_t)r * it.stride];
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T);
     const int L = (int)a.tile_count[(size_t)v * a.T + t];
@@ -226,4 +223,23 @@ __global__ __launch_bounds__(256) void ggs_k_sort_tiles(SortArgs a) {
         for (int i = tid; i < L; i += 256) ids[i] = (uint32_t)keys[i];
     }
     }
+}
+}  // namespace
+
+// K4a: ONE launch for both list classes -- workgroups [0, n_block) sort the long lists (256 threads per tile, first in
+// the grid so they start first), the rest are 4 independent waves each sorting short lists.  As two back-to-back
+// kernels the long-list pass (few, slow workgroups) and the short-list pass could not overlap: 57 -> ~30 us for a
+// single view, where both are latency chains.
+__global__ __launch_bounds__(256) void ggs_k_sort_tiles(SortArgs a, unsigned n_block) {
+    if (a.header->overflow) return;
+    __shared__ unsigned long long s_mem[GGS_SORT_CAP];
+    if (blockIdx.x < n_block) sort_tiles_block_body(a, s_mem, blockIdx.x, n_block);
+    else sort_tiles_wave_body(a, s_mem, blockIdx.x - n_block, gridDim.x - n_block);
+}
+// Short lists only, 16 KB of LDS per workgroup: for launches large enough to fill the chip the short-list waves are
+// throughput bound and want the occupancy the 32 KB of the merged kernel would halve.
+__global__ __launch_bounds__(256) void ggs_k_sort_tiles_wave(SortArgs a) {
+    if (a.header->overflow) return;
+    __shared__ unsigned long long s_mem[4 * GGS_SORT_WAVE_CAP];
+    sort_tiles_wave_body(a, s_mem, blockIdx.x, gridDim.x);
 }

@@ -105,7 +105,7 @@ __global__ void ggs_k_preprocess(PreArgs a);
 __global__ void ggs_k_scan_tiles(ScanArgs a);
 __global__ void ggs_k_scatter(ScatterArgs a);
 __global__ void ggs_k_order_tiles(OrderArgs a);
-__global__ void ggs_k_sort_tiles(SortArgs a);
+__global__ void ggs_k_sort_tiles(SortArgs a, unsigned n_block);
 __global__ void ggs_k_sort_tiles_wave(SortArgs a);
 __global__ void ggs_k_render_fwd(RenderArgs a);
 __global__ void ggs_k_render_fwd_quad(RenderArgs a);

@@ -440,13 +440,18 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
         // Entries of the round the forward blended somewhere in this wave's pixels, as a lane mask (lane i holds entry i):
         // the walk jumps from set bit to set bit on the scalar unit, so an entry that is not ours (21 % of a tile's
         // list, 63 % for a per-quadrant wave) costs nothing -- not even the LDS latency of reading its id word.
+        // (Per-tile waves keep the plain descending loop: they are throughput bound and the mask bookkeeping costs
+        // what the skipped entries save.)
         uint64_t todo = __builtin_amdgcn_ballot_w64((cur.w & my_bits) != 0);
         if (n < 64) todo &= (1ull << n) - 1ull;
-        while (todo) {
-            const int j = 63 - __builtin_clzll(todo);
-            todo &= ~(1ull << j);
+        int jj = n - 1;
+        while (NQ == 1 ? todo != 0 : jj >= 0) {
+            int j;
+            if (NQ == 1) { j = 63 - __builtin_clzll(todo); todo &= ~(1ull << j); }
+            else j = jj--;
             const int pos = first + j;                  // list position; pixel q blended it iff pos < nc[q]
             const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[j]);
+            if (NQ != 1 && !(word & my_bits)) continue; // the forward blended this splat nowhere in this tile
             const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1], rc = s_rec[j * 3 + 2];
             const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y;
             const float cr = rb.z, cg = rb.w, cb = rc.x, dep = rc.y;
