@@ -78,12 +78,20 @@ class GraphAdam:
         gp = ptr(guard)
         b1, b2 = self.betas
         check(L.ggs_adam_tick(ptr(self._state), b1, b2, gp, stream), "ggs_adam_tick")
+        # every tensor that has a gradient, in one launch (ggs_adam_step_multi takes up to 16 per call)
+        items = []
         for i, g in enumerate(self.param_groups):
-            lr = self._lr_dev[i:i + 1]
             for p in g["params"]:
-                if p.grad is None:
+                if p.grad is None or p.numel() == 0:
                     continue
                 grad = p.grad if (p.grad.is_contiguous() and p.grad.dtype == torch.float32) else p.grad.float().contiguous()
                 st = self.state[p]
-                check(L.ggs_adam_step(p.numel(), ptr(p), ptr(grad), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), ptr(lr),
-                                      b1, b2, self.eps, ptr(self._state), gp, stream), "ggs_adam_step")
+                items.append((p.numel(), p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(),
+                              st["exp_avg_sq"].data_ptr(), self._lr_dev.data_ptr() + 4 * i, grad))
+        for k in range(0, len(items), 16):
+            chunk = items[k:k + 16]
+            n = len(chunk)
+            numel = (C.c_size_t * n)(*[c[0] for c in chunk])
+            cols = [(C.c_void_p * n)(*[c[j] for c in chunk]) for j in range(1, 6)]
+            check(L.ggs_adam_step_multi(n, numel, cols[0], cols[1], cols[2], cols[3], cols[4], b1, b2, self.eps,
+                                        ptr(self._state), gp, stream), "ggs_adam_step_multi")
