@@ -117,3 +117,39 @@ def test_graphed_registration_step_matches_eager(slack, lean):
     close(graphed.xyz_gradient_accum, eager.xyz_gradient_accum, 1e-3, 1e-7, "xyz_gradient_accum")
     assert torch.equal(graphed.denom, eager.denom)
     assert torch.equal(graphed.max_radii2D, eager.max_radii2D)
+
+
+@pytest.mark.parametrize("lean", [True, False])
+def test_graphed_mesh_only_step_without_mask(lean):
+    """Later frames of a sequence: only mesh.v is optimised (training_setup(is_ff=False)), no hinge terms, no
+    densification statistics; here also without a foreground mask."""
+    from ggsplat import rasterizer as R
+    from ggsplat.adam import GraphAdam
+    from ggsplat.inner_step import DEFAULT_OPT, GraphedRegistrationStep, registration_step
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "only_foreground_loss": False})
+    v, f, params, cams, gts, masks = _scene(seed=2)
+    bg = torch.ones(3, device="cuda")
+    models = []
+    for graph in (False, True):
+        m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
+        m.training_setup(opt, is_ff=False)
+        m.optimizer.param_groups[0]["lr"] = 1e-3
+        if graph:
+            m.optimizer = GraphAdam(m.optimizer.param_groups, lr=0.0, eps=1e-15)
+        models.append(m)
+    eager, graphed = models
+    R._cap_hint.clear()
+    step = GraphedRegistrationStep(graphed, W, H, bg, opt=opt, first_frame_template=False, use_mask=False, lean=lean)
+    for ci in (0, 2, 4, 1):
+        ref = registration_step(eager, cams[ci], gts[ci], None, bg, opt=opt, first_frame_template=False, fused_loss=True)
+        out = step(cams[ci], gts[ci], None)
+        for k in ("img", "ssim", "loss"):
+            r = float(ref[k].detach())
+            assert abs(float(out[k]) - r) <= 1e-4 * max(1.0, abs(r)), (ci, k)
+    a, b = graphed.mesh.v.detach(), eager.mesh.v.detach()
+    ok = (a - b).abs() <= 2e-6 + 1e-4 * b.abs()
+    assert float(ok.float().mean()) >= 0.995 and float((a - b).abs().mean()) <= 1e-5
+    assert float((a - torch.as_tensor(v, device="cuda")).abs().max()) > 0      # the vertices did move
+    assert torch.equal(graphed._xyz.detach(), eager._xyz.detach())              # nothing else was touched
+    assert float(graphed.denom.abs().max()) == 0.0
