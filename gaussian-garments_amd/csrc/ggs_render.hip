@@ -440,18 +440,70 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
         // Entries of the round the forward blended somewhere in this wave's pixels, as a lane mask (lane i holds entry i):
         // the walk jumps from set bit to set bit on the scalar unit, so an entry that is not ours (21 % of a tile's
         // list, 63 % for a per-quadrant wave) costs nothing -- not even the LDS latency of reading its id word.
-        // (Per-tile waves keep the plain descending loop: they are throughput bound and the mask bookkeeping costs
-        // what the skipped entries save.)
         uint64_t todo = __builtin_amdgcn_ballot_w64((cur.w & my_bits) != 0);
         if (n < 64) todo &= (1ull << n) - 1ull;
-        int jj = n - 1;
-        while (NQ == 1 ? todo != 0 : jj >= 0) {
-            int j;
-            if (NQ == 1) { j = 63 - __builtin_clzll(todo); todo &= ~(1ull << j); }
-            else j = jj--;
+        if constexpr (NQ == 1) {
+            // Latency mapping: two entries per iteration.  Their falloff / alpha evaluations, colour dot products and
+            // the two gradient reductions are independent chains the scheduler interleaves; only the (T, B)
+            // recurrence is sequential (A = the entry further back, then B).
+            auto reduce_add = [&](uint32_t word, float v_mx, float v_my, float v_cx, float v_cy, float v_cz, float v_op,
+                                  float v_r, float v_g, float v_b, float v_dep) {
+                const float Q1 = swap16_add(swap32_add(v_mx, v_my), swap32_add(v_cx, v_cy));
+                const float Q2 = swap16_add(swap32_add(v_cz, v_op), swap32_add(v_r, v_g));
+                const float S = DA ? fold_rows<2>(Q1, Q2, swap32_add(v_b, v_dep)) : fold_rows<4>(Q1, Q2, v_b);
+                float* dst = reinterpret_cast<float*>(acc + (word & GGS_ID_MASK));
+                if (fld >= 0) atomicAdd(dst + fld, S);
+            };
+            while (todo) {
+                const int jA = 63 - __builtin_clzll(todo);
+                todo &= ~(1ull << jA);
+                const bool hasB = todo != 0;
+                const int jB = hasB ? 63 - __builtin_clzll(todo) : jA;
+                if (hasB) todo &= ~(1ull << jB);
+                const uint32_t wordA = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[jA]);
+                const uint32_t wordB = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[jB]);
+                const float4 a0 = s_rec[jA * 3 + 0], a1 = s_rec[jA * 3 + 1], a2 = s_rec[jA * 3 + 2];
+                const float4 b0 = s_rec[jB * 3 + 0], b1 = s_rec[jB * 3 + 1], b2 = s_rec[jB * 3 + 2];
+                // independent of (T, B)
+                const float dxA = a0.x - pxf[0], dyA = a0.y - pyf[0], dxB = b0.x - pxf[0], dyB = b0.y - pyf[0];
+                const float pA = fmaf(a0.z * dxA, dxA, fmaf(a1.x * dyA, dyA, (a0.w * dxA) * dyA));
+                const float pB = fmaf(b0.z * dxB, dxB, fmaf(b1.x * dyB, dyB, (b0.w * dxB) * dyB));
+                const float GrA = __builtin_amdgcn_exp2f(pA), GrB = __builtin_amdgcn_exp2f(pB);
+                const float arA = __builtin_fminf(GGS_ALPHA_MAX, a1.y * GrA), arB = __builtin_fminf(GGS_ALPHA_MAX, b1.y * GrB);
+                const bool validA = (first + jA < nc[0]) & (pA <= 0.f) & (arA >= GGS_ALPHA_MIN);
+                const bool validB = hasB & (first + jB < nc[0]) & (pB <= 0.f) & (arB >= GGS_ALPHA_MIN);
+                float sdotA = fmaf(a2.x, dC2[0], fmaf(a1.w, dC1[0], a1.z * dC0[0]));
+                float sdotB = fmaf(b2.x, dC2[0], fmaf(b1.w, dC1[0], b1.z * dC0[0]));
+                if (DA) { sdotA += fmaf(a2.y, dD[0], dA[0]); sdotB += fmaf(b2.y, dD[0], dA[0]); }
+                const float alA = validA ? arA : 0.f, GA = validA ? GrA : 0.f;
+                const float alB = validB ? arB : 0.f, GB = validB ? GrB : 0.f;
+                const float raA = __builtin_amdgcn_rcpf(1.f - alA), raB = __builtin_amdgcn_rcpf(1.f - alB);
+                // the recurrence: A, then B
+                T[0] *= raA;
+                const float wA = alA * T[0];
+                const float dLA = fmaf(T[0], sdotA, -B[0] * raA);
+                B[0] = fmaf(wA, sdotA, B[0]);
+                T[0] *= raB;
+                const float wB = alB * T[0];
+                const float dLB = fmaf(T[0], sdotB, -B[0] * raB);
+                B[0] = fmaf(wB, sdotB, B[0]);
+                // per-splat sums over this wave's pixels
+                const float tA = GA * dLA, tB = GB * dLB;
+                const float hxA = tA * dxA, hyA = tA * dyA, hxB = tB * dxB, hyB = tB * dyB;
+                reduce_add(wordA, hxA, hyA, hxA * dxA, hxA * dyA, hyA * dyA, tA, wA * dC0[0], wA * dC1[0], wA * dC2[0],
+                           DA ? wA * dD[0] : 0.f);
+                if (hasB)
+                    reduce_add(wordB, hxB, hyB, hxB * dxB, hxB * dyB, hyB * dyB, tB, wB * dC0[0], wB * dC1[0], wB * dC2[0],
+                               DA ? wB * dD[0] : 0.f);
+            }
+            continue;
+        }
+        // Per-tile waves keep the plain descending loop: they are throughput bound and the mask bookkeeping costs
+        // what the skipped entries save.
+        for (int j = n - 1; j >= 0; --j) {
             const int pos = first + j;                  // list position; pixel q blended it iff pos < nc[q]
             const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[j]);
-            if (NQ != 1 && !(word & my_bits)) continue; // the forward blended this splat nowhere in this tile
+            if (!(word & my_bits)) continue;            // the forward blended this splat nowhere in this tile
             const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1], rc = s_rec[j * 3 + 2];
             const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y;
             const float cr = rb.z, cg = rb.w, cb = rc.x, dep = rc.y;
