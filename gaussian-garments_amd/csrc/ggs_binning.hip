@@ -102,14 +102,18 @@ __global__ __launch_bounds__(256) void ggs_k_order_tiles(OrderArgs a) {
 
 namespace {
 
-// sort order = (depth bits, Gaussian id); the quadrant mask riding in bits 28..31 is not part of it
-#define SORT_KEY(k) ((k) & ~((unsigned long long)0xf << GGS_ID_BITS))
+// sort order = (depth bits, Gaussian id): the key is depth << 32 | id << 4 | quadrant mask, so the plain 64-bit
+// comparison already is that order.  The id word handed to the render kernels is mask << 28 | id = the low
+// key word rotated right by 4.
+__device__ __forceinline__ uint32_t key_to_id_word(unsigned long long k) {
+    return __builtin_amdgcn_alignbit((uint32_t)k, (uint32_t)k, 4);
+}
 
 template <typename KeyPtr>
 __device__ __forceinline__ void cmp_exchange(KeyPtr key, int i, int p, int L) {
     if (p < L) {
         const unsigned long long a = key[i], b = key[p];
-        if (SORT_KEY(a) > SORT_KEY(b)) { key[i] = b; key[p] = a; }
+        if (a > b) { key[i] = b; key[p] = a; }
     }
 }
 
@@ -188,7 +192,7 @@ __device__ __forceinline__ void sort_tiles_wave_body(const SortArgs& a, unsigned
             __builtin_amdgcn_wave_barrier();
         }
     }
-    for (int i = lane; i < L; i += 64) ids[i] = (uint32_t)key[i];
+    for (int i = lane; i < L; i += 64) ids[i] = key_to_id_word(key[i]);
     }
 }
 
@@ -214,13 +218,13 @@ __device__ __forceinline__ void sort_tiles_block_body(const SortArgs& a, unsigne
         __syncthreads();
         bitonic_sort<unsigned long long*, true>(s_key, L, n2, tid);
         __syncthreads();
-        for (int i = tid; i < L; i += 256) ids[i] = (uint32_t)s_key[i];
+        for (int i = tid; i < L; i += 256) ids[i] = key_to_id_word(s_key[i]);
     } else {
         // Oversized list (pathological: > 4096 splats on one 16x16 tile): same network on the
         // global segment.  Slow but exact; plain loads/stores are ordered by __syncthreads
         // inside one workgroup (same CU, same L1).
         bitonic_sort<unsigned long long*, false>(keys, L, n2, tid);
-        for (int i = tid; i < L; i += 256) ids[i] = (uint32_t)keys[i];
+        for (int i = tid; i < L; i += 256) ids[i] = key_to_id_word(keys[i]);
     }
     }
 }

@@ -7,7 +7,7 @@
 //          SplatAux aux[V][P]           16 B: radius + SH clamp bits + reachable-tile bitmask (binning / backward only).
 //   bin  : BinHeader | tile_count[V][T] | tile_cursor[V][T] | tile_offset[V][T] |
 //          view_base[V] | order[V*T] (work items v*T+t, heaviest tile lists first) |
-//          keys[cap] (u64: depth bits << 32 | quadrant mask << 28 | Gaussian id) | ids[cap] (u32:
+//          keys[cap] (u64: depth bits << 32 | Gaussian id << 4 | quadrant mask) | ids[cap] (u32:
 //          quadrant mask << 28 | id, sorted by (depth bits, id))
 //          (BinHeader bytes 64.. hold the 8 list-length bucket counters / cursors of `order`)
 //   img  : final_T[V][H*W] f32 | n_contrib[V][H*W] u32

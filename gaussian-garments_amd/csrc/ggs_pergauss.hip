@@ -191,8 +191,9 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
 }
 
 // K3: grid (ceil(P/256), V).  For every (splat, tile) instance take a slot in the tile's
-// segment and write the 64-bit key (depth bits << 32 | id).  Slot order is arbitrary;
-// the per-tile sort makes the final order (depth, id) deterministic.
+// segment and write the 64-bit key  depth bits << 32 | id << 4 | quadrant mask  -- the mask sits BELOW the id so
+// that plain 64-bit comparisons order by (depth, id) without masking anything out (an id occurs once per tile).
+// Slot order is arbitrary; the per-tile sort makes the final order deterministic.
 __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
     if (a.header->overflow) return;
     __shared__ int s_box[4];
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
             bbx = __float_as_uint(r2.z); bby = __float_as_uint(r2.w);
             fp = ggs_footprint(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
             ggs_cull_rect(bbx, bby, x0, y0, x1, y1);
-            key = ((unsigned long long)__float_as_uint(r2.y) << 32) | (unsigned)g;
+            key = ((unsigned long long)__float_as_uint(r2.y) << 32) | ((unsigned)g << 4);   // low nibble: quadrant mask
             has = x0 < x1 && y0 < y1;
         }
     }
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
                     if (!member(idx, x, y)) continue;
                     const unsigned long long qm = ggs_quad_mask(fp, bbx, bby, x, y);
                     const int i = (y - w.y0) * w.w + (x - w.x0);
-                    keys[(size_t)s_base[i] + atomicAdd(&s_cnt[i], 1u)] = key | qm;
+                    keys[(size_t)s_base[i] + atomicAdd(&s_cnt[i], 1u)] = key | (qm >> GGS_ID_BITS);
                 }
     } else if (has) {
         for (int y = y0; y < y1; ++y)
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
                 const unsigned long long qm = ggs_quad_mask(fp, bbx, bby, x, y);
                 const int t = y * a.gx + x;
                 const uint32_t slot = atomicAdd(&cur[t], 1u);
-                keys[(size_t)off[t] + slot] = key | qm;
+                keys[(size_t)off[t] + slot] = key | (qm >> GGS_ID_BITS);
             }
     }
 }
