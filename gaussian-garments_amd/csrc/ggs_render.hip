@@ -129,11 +129,10 @@ namespace {
 // a single view has ~1.1k non-empty tiles of ~300 splats for 1024 SIMDs and is bounded by the serial walk of its
 // longest tile -- is render_fwd_quadwave below; the backward keeps both mappings in one template.)
 // Same arithmetic per pixel, bit-identical results.
-template <int NQ>
 __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
+    constexpr int NQ = 4, q0 = 0;
     if (a.header->overflow) return;
-    const uint32_t item = a.order[NQ == 4 ? blockIdx.x : blockIdx.x >> 2];   // work items, longest lists first
-    const int q0 = NQ == 4 ? 0 : (int)(blockIdx.x & 3);
+    const uint32_t item = a.order[blockIdx.x];   // work items, longest lists first
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
     const int tx = t % a.gx, ty = t / a.gx;
     const int ox = tx * GGS_TILE, oy = ty * GGS_TILE;
@@ -213,16 +212,10 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
                     // superset of "some pixel blended it" -- the backward re-tests every pixel -- at no VALU cost)
                     blended |= 1u << (GGS_ID_BITS + q0 + q);
                 }
-                if (NQ == 4) {
-                    if (lane == j) neww |= blended;
-                } else {
-                    // four waves share the word: each clears only its own quadrant bit, atomically
-                    const uint32_t mine = 1u << (GGS_ID_BITS + q0);
-                    if ((word & mine) && !blended && lane == 0) atomicAnd(&ids[first + j], ~mine);
-                }
+                if (lane == j) neww |= blended;
                 if (remaining == 0) break;
             }
-            if (NQ == 4 && lane < n) ids[first + lane] = neww;
+            if (lane < n) ids[first + lane] = neww;
         }
     }
 
@@ -356,7 +349,7 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
 }  // namespace
 
 // K4b: grid V*T work items (x4 for the per-quadrant variant), block 64.
-__global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) { render_fwd_body<4>(a); }
+__global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) { render_fwd_body(a); }
 __global__ __launch_bounds__(64) void ggs_k_render_fwd_quad(RenderArgs a) { render_fwd_quadwave(a); }
 
 namespace {
