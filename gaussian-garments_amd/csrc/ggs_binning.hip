@@ -149,50 +149,127 @@ __device__ __forceinline__ void bitonic_sort(KeyPtr key, int L, int n2, int tid)
 }  // namespace
 
 // K4a-small: persistent grid, block 256 = 4 independent wave64s, ONE TILE PER WAVE for lists of up to
-// GGS_SORT_WAVE_CAP keys: each wave sorts in its private 4 KB LDS slice with the whole network
-// wave-local -- no workgroup barrier at all, and every lane carries n2/128 independent
-// compare-exchanges per sub-step (ILP hides the LDS latency the 256-thread version exposed).
-#define GGS_SORT_WAVE_CAP 512
+// GGS_SORT_WAVE_CAP keys, sorted IN REGISTERS: lane l holds the E = n2 / 64 consecutive keys [l E, l E + E) of the
+// (+inf padded) list.  Of the 45 sub-steps of the 512-key bitonic network 24 have both partners in the same lane
+// (compare + 4 selects, no memory at all); in the other 21 the partner key comes from lane l ^ x through the LDS
+// crossbar (ds_swizzle / ds_bpermute: no LDS memory, no bank conflicts) and each lane keeps the minimum or the
+// maximum.  ~1000 VALU + 340 crossbar ops per 512 keys against ~3200 VALU + 720 64-bit LDS reads / writes for the
+// network run out of an LDS array; no barriers of any kind.
+#define GGS_SORT_WAVE_CAP 1024
 namespace {
-__device__ __forceinline__ void sort_tiles_wave_body(const SortArgs& a, unsigned long long* s_mem, uint32_t bid, uint32_t nblk) {
+
+template <int X>
+__device__ __forceinline__ uint32_t lane_xor_get(uint32_t v, int lane) {
+    if constexpr (X < 32) return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x1F | (X << 10));   // bit-mask mode: xor X
+    else return (uint32_t)__builtin_amdgcn_ds_bpermute((lane ^ X) << 2, (int)v);
+}
+__device__ __forceinline__ unsigned long long lane_xor_get64(unsigned long long k, int x, int lane) {
+    uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+    switch (x) {                         // x is a compile-time constant after unrolling
+        case 1: lo = lane_xor_get<1>(lo, lane); hi = lane_xor_get<1>(hi, lane); break;
+        case 2: lo = lane_xor_get<2>(lo, lane); hi = lane_xor_get<2>(hi, lane); break;
+        case 3: lo = lane_xor_get<3>(lo, lane); hi = lane_xor_get<3>(hi, lane); break;
+        case 4: lo = lane_xor_get<4>(lo, lane); hi = lane_xor_get<4>(hi, lane); break;
+        case 7: lo = lane_xor_get<7>(lo, lane); hi = lane_xor_get<7>(hi, lane); break;
+        case 8: lo = lane_xor_get<8>(lo, lane); hi = lane_xor_get<8>(hi, lane); break;
+        case 15: lo = lane_xor_get<15>(lo, lane); hi = lane_xor_get<15>(hi, lane); break;
+        case 16: lo = lane_xor_get<16>(lo, lane); hi = lane_xor_get<16>(hi, lane); break;
+        case 31: lo = lane_xor_get<31>(lo, lane); hi = lane_xor_get<31>(hi, lane); break;
+        case 32: lo = lane_xor_get<32>(lo, lane); hi = lane_xor_get<32>(hi, lane); break;
+        default: lo = lane_xor_get<63>(lo, lane); hi = lane_xor_get<63>(hi, lane); break;
+    }
+    return ((unsigned long long)hi << 32) | lo;
+}
+// lanes whose bit `b` is clear: the lower partner of a pair (lane, lane ^ x) with b the top bit of x
+__device__ __forceinline__ unsigned long long lower_lanes(int b) {
+    return b == 1 ? 0x5555555555555555ull : b == 2 ? 0x3333333333333333ull : b == 4 ? 0x0F0F0F0F0F0F0F0Full
+         : b == 8 ? 0x00FF00FF00FF00FFull : b == 16 ? 0x0000FFFF0000FFFFull : 0x00000000FFFFFFFFull;
+}
+__device__ __forceinline__ uint32_t sel_u32(unsigned long long m, uint32_t a, uint32_t b) {           // m ? a : b
+    uint32_t r;
+    asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m));
+    return r;
+}
+
+// one sub-step whose partner lives in lane ^ X: register r meets register (MIRROR ? E - 1 - r : r) of that lane;
+// B = top bit of X decides which lane of the pair is the lower one
+template <int E, int X, int B, bool MIRROR>
+__device__ __forceinline__ void sort_cross(unsigned long long (&k)[E], int lane) {
+    const unsigned long long lower = lower_lanes(B);
+    unsigned long long o[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) o[r] = lane_xor_get64(k[MIRROR ? E - 1 - r : r], X, lane);
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        // the lower lane keeps the smaller key: take the partner's iff (mine > other) == lower
+        const unsigned long long take = ~(__builtin_amdgcn_ballot_w64(k[r] > o[r]) ^ lower);
+        const uint32_t lo = sel_u32(take, (uint32_t)o[r], (uint32_t)k[r]);
+        const uint32_t hi = sel_u32(take, (uint32_t)(o[r] >> 32), (uint32_t)(k[r] >> 32));
+        k[r] = ((unsigned long long)hi << 32) | lo;
+    }
+}
+// both partners in this lane: registers (r, r ^ XR) for the r whose bit BIT is clear; the lower index keeps the minimum
+template <int E, int XR, int BIT>
+__device__ __forceinline__ void sort_local(unsigned long long (&k)[E]) {
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        if ((r & BIT) != 0) continue;
+        const unsigned long long x = k[r], y = k[r ^ XR];
+        const bool gt = x > y;
+        k[r] = gt ? y : x; k[r ^ XR] = gt ? x : y;
+    }
+}
+template <int E, int J>
+__device__ __forceinline__ void sort_half_cleaners(unsigned long long (&k)[E], int lane) {   // distances J, J/2, ..., 1
+    if constexpr (J >= 1) {
+        if constexpr (J < E) sort_local<E, J, J>(k);
+        else sort_cross<E, J / E, J / E, false>(k, lane);
+        sort_half_cleaners<E, J / 2>(k, lane);
+    }
+}
+template <int E, int KK>
+__device__ __forceinline__ void sort_phases(unsigned long long (&k)[E], int lane) {          // merge phases KK, 2 KK, ... 64 E
+    if constexpr (KK <= 64 * E) {
+        // flip step: mirror inside aligned blocks of KK keys, then the half cleaners
+        if constexpr (KK <= E) sort_local<E, KK - 1, KK / 2>(k);
+        else sort_cross<E, KK / E - 1, KK / (2 * E), true>(k, lane);
+        sort_half_cleaners<E, KK / 4>(k, lane);
+        sort_phases<E, KK * 2>(k, lane);
+    }
+}
+template <int E>
+__device__ __forceinline__ void wave_sort_regs(unsigned long long (&k)[E], int lane) { sort_phases<E, 2>(k, lane); }
+
+template <int E>
+__device__ __forceinline__ void sort_one_tile_regs(const unsigned long long* __restrict__ keys, uint32_t* __restrict__ ids,
+                                                   int L, int lane) {
+    unsigned long long k[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) k[r] = lane * E + r < L ? keys[lane * E + r] : ~0ull;     // +inf padding sorts last
+    wave_sort_regs<E>(k, lane);
+#pragma unroll
+    for (int r = 0; r < E; ++r)
+        if (lane * E + r < L) ids[lane * E + r] = key_to_id_word(k[r]);
+}
+
+__device__ __forceinline__ void sort_tiles_wave_body(const SortArgs& a, uint32_t bid, uint32_t nblk) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const NonEmptyItems it = ggs_nonempty_items(a.bucket_count, (uint32_t)a.n_items);
-    unsigned long long* key = s_mem + wave * GGS_SORT_WAVE_CAP;
     // persistent waves over the non-empty work items only (the empty ~90 % of an image never cost a
     // workgroup launch); round-robin over a longest-first list keeps the waves evenly loaded
     for (uint32_t r = bid * 4 + wave; r < it.n; r += nblk * 4) {
-    const uint32_t item = a.order[(size_t)r * it.stride];
-    const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T);
-    const int L = (int)a.tile_count[(size_t)v * a.T + t];
-    if (L > GGS_SORT_WAVE_CAP) continue;                  // longer lists: ggs_k_sort_tiles
-    const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
-    const unsigned long long* keys = a.keys + base;
-    uint32_t* ids = a.ids + base;
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < L; i += 64) key[i] = keys[i];
-    __builtin_amdgcn_wave_barrier();
-    int n2 = 2;
-    while (n2 < L) n2 <<= 1;
-    const int half = n2 >> 1;
-    for (int lk = 1; (1 << lk) <= n2; ++lk) {
-        const int k = 1 << lk, lhk = lk - 1;
-#pragma unroll 4
-        for (int p = lane; p < half; p += 64) {
-            const int blk = p >> lhk, o = p & ((1 << lhk) - 1);
-            cmp_exchange(key, (blk << lk) + o, (blk << lk) + k - 1 - o, L);
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int lj = lk - 2; lj >= 0; --lj) {
-            const int j = 1 << lj;
-#pragma unroll 4
-            for (int p = lane; p < half; p += 64) {
-                const int i = ((p >> lj) << (lj + 1)) + (p & (j - 1));
-                cmp_exchange(key, i, i + j, L);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-    for (int i = lane; i < L; i += 64) ids[i] = key_to_id_word(key[i]);
+        const uint32_t item = a.order[(size_t)r * it.stride];
+        const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T);
+        const int L = (int)a.tile_count[(size_t)v * a.T + t];
+        if (L > GGS_SORT_WAVE_CAP) continue;                  // longer lists: the workgroup variant
+        const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
+        const unsigned long long* keys = a.keys + base;
+        uint32_t* ids = a.ids + base;
+        if (L <= 64) sort_one_tile_regs<1>(keys, ids, L, lane);
+        else if (L <= 128) sort_one_tile_regs<2>(keys, ids, L, lane);
+        else if (L <= 256) sort_one_tile_regs<4>(keys, ids, L, lane);
+        else if (L <= 512) sort_one_tile_regs<8>(keys, ids, L, lane);
+        else sort_one_tile_regs<16>(keys, ids, L, lane);
     }
 }
 
@@ -238,12 +315,11 @@ __global__ __launch_bounds__(256) void ggs_k_sort_tiles(SortArgs a, unsigned n_b
     if (a.header->overflow) return;
     __shared__ unsigned long long s_mem[GGS_SORT_CAP];
     if (blockIdx.x < n_block) sort_tiles_block_body(a, s_mem, blockIdx.x, n_block);
-    else sort_tiles_wave_body(a, s_mem, blockIdx.x - n_block, gridDim.x - n_block);
+    else sort_tiles_wave_body(a, blockIdx.x - n_block, gridDim.x - n_block);
 }
-// Short lists only, 16 KB of LDS per workgroup: for launches large enough to fill the chip the short-list waves are
-// throughput bound and want the occupancy the 32 KB of the merged kernel would halve.
+// Short lists only, no LDS: for launches large enough to fill the chip the short-list waves are throughput bound and
+// want the occupancy the 32 KB of the merged kernel would cap.
 __global__ __launch_bounds__(256) void ggs_k_sort_tiles_wave(SortArgs a) {
     if (a.header->overflow) return;
-    __shared__ unsigned long long s_mem[4 * GGS_SORT_WAVE_CAP];
-    sort_tiles_wave_body(a, s_mem, blockIdx.x, gridDim.x);
+    sort_tiles_wave_body(a, blockIdx.x, gridDim.x);
 }
