@@ -201,15 +201,15 @@ __device__ __forceinline__ float ggs_edge_min_y(const Footprint& f, float ye, fl
 }
 // Only the edges FACING the mean can hold the minimum: from any point of the box the segment to the mean
 // decreases q and leaves the box through one of them.
+// Branch-free: ONE vertical and ONE horizontal edge are always evaluated -- the facing one where there is one, else
+// an arbitrary one, whose minimum is the value at a box point and therefore >= the box minimum (harmless in the min).
+// Neighbouring lanes sit in different regions around the splat, so the branchy form executed all four edge blocks.
 __device__ __forceinline__ bool ggs_box_reachable(const Footprint& f, float x0, float y0, float x1, float y1) {
     const bool left = f.mx < x0, right = f.mx > x1, above = f.my < y0, below = f.my > y1;
-    if (!(left || right || above || below)) return f.lim > 0.f;          // mean inside the box
-    float q = 3.0e38f;
-    if (left) q = ggs_edge_min_x(f, x0, y0, y1);
-    if (right) q = ggs_edge_min_x(f, x1, y0, y1);
-    if (above) q = ggs_min(q, ggs_edge_min_y(f, y0, x0, x1));
-    if (below) q = ggs_min(q, ggs_edge_min_y(f, y1, x0, x1));
-    return q <= f.lim;
+    const float qv = ggs_edge_min_x(f, right ? x1 : x0, y0, y1);
+    const float qh = ggs_edge_min_y(f, below ? y1 : y0, x0, x1);
+    const bool inside = !(left | right | above | below);                 // mean inside the box: q = 0 there
+    return inside ? f.lim > 0.f : ggs_min(qv, qh) <= f.lim;
 }
 
 // Which 8x8 quadrants of tile (tx, ty) the splat can be blended in, positioned at bits 28..31 of the id word;
