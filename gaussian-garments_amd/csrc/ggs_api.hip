@@ -80,6 +80,10 @@ int check_params(const GgsParams* p) {
     if (p->n_views > 65535) return fail(GGS_ERR_SIZE, "n_views=%d exceeds the grid.y limit 65535", p->n_views);
     if ((size_t)p->P * (size_t)p->n_views > (size_t)1 << 40) return fail(GGS_ERR_SIZE, "P*n_views too large");
     if (p->P >= (1 << GGS_ID_BITS)) return fail(GGS_ERR_SIZE, "P=%d exceeds the 2^28 id space of the tile lists", p->P);
+    if (p->W > 32767 || p->H > 32767) return fail(GGS_ERR_SIZE, "image %dx%d exceeds the 16-bit pixel boxes of the records", p->W, p->H);
+    const size_t tiles = (size_t)((p->W + GGS_TILE - 1) / GGS_TILE) * (size_t)((p->H + GGS_TILE - 1) / GGS_TILE);
+    if (tiles * (size_t)p->n_views >= ((size_t)1 << 31))
+        return fail(GGS_ERR_SIZE, "n_views * tiles = %zu work items exceed the launch grid", tiles * (size_t)p->n_views);
     return GGS_OK;
 }
 

@@ -21,7 +21,6 @@ from __future__ import annotations
 
 import ctypes as C
 from types import SimpleNamespace
-from typing import Optional
 
 import torch
 from torch import nn
