@@ -34,6 +34,17 @@ def last_header() -> Optional[torch.Tensor]:
     return _last_header
 
 
+# headers of the forwards issued while a stream was being captured (the graph owner checks their overflow words)
+_capture_headers: list = []
+
+
+def pop_capture_headers() -> list:
+    """Device int64[2] headers {num_rendered, overflow} of every forward captured since the last call."""
+    out = list(_capture_headers)
+    _capture_headers.clear()
+    return out
+
+
 def grow_capacity(factor: float = 2.0) -> None:
     """Enlarge every learnt binning capacity (a captured step reported overflow: re-capture after this)."""
     for k in list(_cap_hint):
@@ -157,6 +168,8 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
         # phase 2: scatter + sort + composite, queued without waiting
         check(L.ggs_forward_render(*args), "ggs_forward_render")
     _last_header = binb[:16].view(torch.int64)
+    if capturing:
+        _capture_headers.append(_last_header)
     st = None
     if keep_state:
         st = ForwardState()
