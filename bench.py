@@ -140,8 +140,15 @@ def main():
         from ggsplat import rasterizer as R
         R.pop_capture_headers()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            grads = compute()
+        try:
+            # thread_local: API calls of other threads (the RCCL watchdog polling its events) cannot invalidate the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                grads = compute()
+        except Exception as e:                   # stay on the eager launches (same kernels) rather than fail the run
+            print(f"[bench] graph capture failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr, flush=True)
+            torch.cuda.synchronize(dev)
+            R.pop_capture_headers()
+            return
         graph.update(g=g, grads=grads, headers=R.pop_capture_headers())
 
     def sync():
