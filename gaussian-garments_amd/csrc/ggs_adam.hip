@@ -12,14 +12,19 @@
 
 namespace {
 
-struct AdamState { long long step; float bias1; float bias2_sqrt; };   // 16 bytes, device
+struct AdamState { long long step; float bias1; float bias2_sqrt; double pow1; double pow2; };   // 32 bytes, device
 
 __global__ void k_adam_tick(AdamState* s, double beta1, double beta2, const unsigned long long* guard) {
     if (guard && *guard) return;
     const long long t = s->step + 1;
     s->step = t;
-    s->bias1 = (float)(1.0 - pow(beta1, (double)t));                   // torch computes these in Python floats
-    s->bias2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)t));
+    // beta^t as a running double product (torch evaluates beta ** step in Python floats each step; the products agree to
+    // ~t * 2^-53, far below the fp32 the corrections are used in) -- a device-side pow() made this one-thread kernel
+    // the slowest launch of a graph-replayed iteration after the rasterizer and the loss
+    const double p1 = t == 1 ? beta1 : s->pow1 * beta1, p2 = t == 1 ? beta2 : s->pow2 * beta2;
+    s->pow1 = p1; s->pow2 = p2;
+    s->bias1 = (float)(1.0 - p1);
+    s->bias2_sqrt = (float)sqrt(1.0 - p2);
 }
 
 struct AdamArgs {
