@@ -42,9 +42,18 @@ struct TileWindow { int x0, y0, w, h; bool dense; };
 __device__ __forceinline__ TileWindow block_tile_window(int* s_box, bool has, int x0, int y0, int x1, int y1) {
     if (threadIdx.x == 0) { s_box[0] = 0x7fffffff; s_box[1] = 0x7fffffff; s_box[2] = -0x7fffffff; s_box[3] = -0x7fffffff; }
     __syncthreads();
-    if (has) {
-        atomicMin(&s_box[0], x0); atomicMin(&s_box[1], y0);
-        atomicMax(&s_box[2], x1); atomicMax(&s_box[3], y1);
+    // Wave reduction first, one LDS atomic per wave and bound.  (Plain per-lane LDS atomicMin / atomicMax are turned by
+    // the compiler into a serial v_readlane loop over the 64 lanes: 4 x 64 x 7 scalar instructions per wave -- it was
+    // most of this kernel's SALU stream.)
+    int bx0 = has ? x0 : 0x7fffffff, by0 = has ? y0 : 0x7fffffff, bx1 = has ? x1 : -0x7fffffff, by1 = has ? y1 : -0x7fffffff;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        bx0 = min(bx0, __shfl_xor(bx0, d)); by0 = min(by0, __shfl_xor(by0, d));
+        bx1 = max(bx1, __shfl_xor(bx1, d)); by1 = max(by1, __shfl_xor(by1, d));
+    }
+    if ((threadIdx.x & 63) == 0 && bx0 != 0x7fffffff) {
+        atomicMin(&s_box[0], bx0); atomicMin(&s_box[1], by0);
+        atomicMax(&s_box[2], bx1); atomicMax(&s_box[3], by1);
     }
     __syncthreads();
     TileWindow w;
