@@ -416,6 +416,9 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
     // wave max of the per-pixel contributor counts
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
+    // tell the compiler the maximum is wave-uniform: otherwise the walk below becomes a per-lane loop (VGPR counter,
+    // exec-mask bookkeeping: 4 VALU per list entry, skipped ones included)
+    maxc = __builtin_amdgcn_readfirstlane(maxc);
     if (maxc == 0) return;
 
     __shared__ float4 s_rec[64 * 3];
