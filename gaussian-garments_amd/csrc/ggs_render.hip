@@ -111,11 +111,9 @@ __device__ __forceinline__ Rec3 gather_round(const float4* __restrict__ rec, con
 // would take VALU issue slots.  One wave per workgroup: no barrier, only the compiler fence.
 struct RoundLds {
     float4* rec;          // [64][3]
-    uint32_t* w;          // [64]
     __device__ __forceinline__ void put(const Rec3& r, int lane) {
         __builtin_amdgcn_wave_barrier();
         rec[lane * 3 + 0] = r.a; rec[lane * 3 + 1] = r.b; rec[lane * 3 + 2] = r.c;
-        w[lane] = r.w;
         __builtin_amdgcn_wave_barrier();
     }
 };
@@ -157,8 +155,7 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
     }
 
     __shared__ float4 s_rec[64 * 3];
-    __shared__ uint32_t s_w[64];
-    RoundLds lds{s_rec, s_w};
+    RoundLds lds{s_rec};
     // pixels of this wave still compositing: a wave-uniform counter kept on the scalar unit (s_bcnt1 of the stop
     // mask), so the walk ends at the very splat that finishes the tile without any per-splat VALU test
     const float inf_v = __builtin_inff();
@@ -177,7 +174,7 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
             uint32_t neww = cur.w & GGS_ID_MASK;
             lds.put(cur, lane);
             for (int j = 0; j < n; ++j) {
-                const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[j]);
+                const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, j);   // lane j gathered entry j
                 uint32_t blended = 0;
                 const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1], rc = s_rec[j * 3 + 2];
                 const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y;
@@ -263,8 +260,7 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
     const uint32_t mine = 1u << (GGS_ID_BITS + q0);
 
     __shared__ float4 s_rec[64 * 3];
-    __shared__ uint32_t s_w[64];
-    RoundLds lds{s_rec, s_w};
+    RoundLds lds{s_rec};
     if (L > 0) {
         Rec3 nxt = gather_round(rec, ids, 0, L, lane);
         for (int first = 0; first < L && remaining != 0; first += 64) {
@@ -422,8 +418,7 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
     if (maxc == 0) return;
 
     __shared__ float4 s_rec[64 * 3];
-    __shared__ uint32_t s_w[64];
-    RoundLds lds{s_rec, s_w};
+    RoundLds lds{s_rec};
     // rounds of 64 list positions, walked from the back: round r covers [64 r, 64 r + 64)
     int r = (maxc - 1) >> 6;
     Rec3 nxt = gather_round(rec, ids, r * 64, L, lane);
@@ -456,8 +451,8 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
                 const bool hasB = todo != 0;
                 const int jB = hasB ? 63 - __builtin_clzll(todo) : jA;
                 if (hasB) todo &= ~(1ull << jB);
-                const uint32_t wordA = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[jA]);
-                const uint32_t wordB = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[jB]);
+                const uint32_t wordA = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, jA);
+                const uint32_t wordB = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, jB);
                 const float4 a0 = s_rec[jA * 3 + 0], a1 = s_rec[jA * 3 + 1], a2 = s_rec[jA * 3 + 2];
                 const float4 b0 = s_rec[jB * 3 + 0], b1 = s_rec[jB * 3 + 1], b2 = s_rec[jB * 3 + 2];
                 // independent of (T, B)
@@ -498,7 +493,7 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
         // what the skipped entries save.
         for (int j = n - 1; j >= 0; --j) {
             const int pos = first + j;                  // list position; pixel q blended it iff pos < nc[q]
-            const uint32_t word = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_w[j]);
+            const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, j);   // lane j gathered entry j
             if (!(word & my_bits)) continue;            // the forward blended this splat nowhere in this tile
             const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1], rc = s_rec[j * 3 + 2];
             const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y;
