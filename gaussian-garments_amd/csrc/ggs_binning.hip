@@ -253,7 +253,8 @@ __device__ __forceinline__ void sort_one_tile_regs(const unsigned long long* __r
 }
 
 __device__ __forceinline__ void sort_tiles_wave_body(const SortArgs& a, uint32_t bid, uint32_t nblk) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is uniform by construction; saying so keeps the item loop, its loads and the length dispatch scalar
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const NonEmptyItems it = ggs_nonempty_items(a.bucket_count, (uint32_t)a.n_items);
     // persistent waves over the non-empty work items only (the empty ~90 % of an image never cost a
     // workgroup launch); round-robin over a longest-first list keeps the waves evenly loaded
