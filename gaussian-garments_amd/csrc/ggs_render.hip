@@ -169,13 +169,16 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
             const Rec3 cur = nxt;
             if (first + 64 < L) nxt = gather_round(rec, ids, first + 64, L, lane);
             const int n = min(64, L - first);
-            // id words of this round with the quadrant mask narrowed to the quadrants that actually blended
-            // the splat (0 for splats not reached): the backward skips everything else without testing
-            uint32_t neww = cur.w & GGS_ID_MASK;
+            // The id words of this round are rewritten with the quadrant mask narrowed to the quadrants that actually
+            // blended the splat (0 for splats not reached): the backward skips everything else without testing.  The
+            // narrowed masks are collected as four 64-bit bit planes (bit j of plane q: entry j blended in quadrant q) on
+            // the scalar unit -- updating lane j of a VGPR per entry costs a compare, a move, a select and an or.
+            uint64_t plane[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) plane[q] = 0;
             lds.put(cur, lane);
             for (int j = 0; j < n; ++j) {
                 const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, j);   // lane j gathered entry j
-                uint32_t blended = 0;
                 const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1], rc = s_rec[j * 3 + 2];
                 const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y;
                 const float cr = rb.z, cg = rb.w, cb = rc.x, dep = rc.y;
@@ -207,11 +210,13 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
                     last[q] = __float_as_uint(sel(m_app, __uint_as_float(posv), __uint_as_float(last[q])));
                     // some pixel of the quadrant passed the alpha test: keep the quadrant in the backward's mask (a
                     // superset of "some pixel blended it" -- the backward re-tests every pixel -- at no VALU cost)
-                    blended |= 1u << (GGS_ID_BITS + q0 + q);
+                    plane[q] |= 1ull << j;
                 }
-                if (lane == j) neww |= blended;
                 if (remaining == 0) break;
             }
+            uint32_t neww = cur.w & GGS_ID_MASK;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) neww |= ((uint32_t)(plane[q] >> lane) & 1u) << (GGS_ID_BITS + q);
             if (lane < n) ids[first + lane] = neww;
         }
     }
