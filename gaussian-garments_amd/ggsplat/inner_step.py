@@ -17,7 +17,8 @@ from .loss import fused_photometric_loss, l1_loss, ssim
 from .render import render
 
 DEFAULT_OPT = SimpleNamespace(                      # arguments/__init__.py:74-116 (the values the steps read)
-    position_lr_init=0.00016, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001,
+    position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01, position_lr_max_steps=30_000,
+    feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001,
     percent_dense=0.01, lambda_dssim=0.2, lambda_xyz=1e-2, threshold_xyz=1.0, lambda_scale=1.0,
     threshold_scale=0.6, threshold_opacity=0.75, lambda_opacity=0.01, only_foreground_loss=True)
 DEFAULT_PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)

@@ -221,6 +221,27 @@ class MeshGaussianModel:
         else:                                   # non-first frames optimise the mesh only
             groups = [{"params": [self.mesh.v], "lr": pos_lr, "name": "vertex"}]
         self.optimizer = torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        from .schedule import get_expon_lr_func
+        self.xyz_scheduler_args = get_expon_lr_func(
+            lr_init=pos_lr, lr_final=getattr(training_args, "position_lr_final", 0.0000016) * self.spatial_lr_scale,
+            lr_delay_mult=getattr(training_args, "position_lr_delay_mult", 0.01),
+            max_steps=getattr(training_args, "position_lr_max_steps", 30_000))
+
+    def update_learning_rate(self, iteration: int):
+        """scene/gaussian_model.py:171-177: the schedule drives the group named "xyz" (only).  With a GraphAdam the new
+        rate is also uploaded to the device, where a captured step reads it."""
+        for group in self.optimizer.param_groups:
+            if group["name"] == "xyz":
+                lr = self.xyz_scheduler_args(iteration)
+                group["lr"] = lr
+                if hasattr(self.optimizer, "push_lr"):
+                    self.optimizer.push_lr()
+                return lr
+
+    def oneupSHdegree(self):
+        """scene/gaussian_model.py:121-123."""
+        if self.active_sh_degree < self.max_sh_degree:
+            self.active_sh_degree += 1
 
     def add_densification_stats(self, viewspace_point_tensor, update_filter, ok=None):
         """scene/gaussian_model.py:410-412, written with masks instead of boolean indexing (no host sync, so the

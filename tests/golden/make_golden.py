@@ -137,6 +137,27 @@ def stylegan_golden():
     np.savez(os.path.join(OUT, "stylegan_ops.npz"), **rec)
 
 
+def schedule_golden():
+    """get_expon_lr_func (utils/general_utils.py:39-74).  The module imports open3d and scene.cameras at import time:
+    empty stand-ins are registered for those names (nothing of them is called by the schedule)."""
+    import types
+    for name in ("open3d", "scene", "scene.cameras"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["scene.cameras"].Camera = object
+    from utils.general_utils import get_expon_lr_func
+    steps = np.array([-1, 0, 1, 10, 99, 100, 500, 1000, 7000, 15000, 29999, 30000, 45000])
+    cfgs = {"s2_xyz": dict(lr_init=0.00016, lr_final=0.0000016, lr_delay_mult=0.01, max_steps=30_000),
+            "delayed": dict(lr_init=0.01, lr_final=0.0001, lr_delay_steps=500, lr_delay_mult=0.1, max_steps=10_000),
+            "off": dict(lr_init=0.0, lr_final=0.0)}
+    rec = {"steps": steps}
+    for name, kw in cfgs.items():
+        f = get_expon_lr_func(**kw)
+        rec[name] = np.array([float(f(int(t))) for t in steps], dtype=np.float64)
+        rec[name + "_cfg"] = np.array([kw.get("lr_init"), kw.get("lr_final"), kw.get("lr_delay_steps", 0),
+                                       kw.get("lr_delay_mult", 1.0), kw.get("max_steps", 1000000)], dtype=np.float64)
+    np.savez(os.path.join(OUT, "lr_schedule.npz"), **rec)
+
+
 if __name__ == "__main__":
-    sh_golden(); camera_golden(); face_golden(); loss_golden(); stylegan_golden()
+    sh_golden(); camera_golden(); face_golden(); loss_golden(); stylegan_golden(); schedule_golden()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))

@@ -139,3 +139,14 @@ def test_cov3d_matches_reference_python_path():
     S = Lm @ Lm.transpose(1, 2)
     ref = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1)
     assert np.allclose(TO.cov3d_from_scale_rot(s, 1.3, q).numpy(), ref.numpy(), rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize("name", ["s2_xyz", "delayed", "off"])
+def test_lr_schedule_matches_reference(name):
+    """get_expon_lr_func (utils/general_utils.py:39-74) -- the position learning-rate schedule of training_setup."""
+    from ggsplat.schedule import get_expon_lr_func
+    d = _load("lr_schedule.npz")
+    lr_init, lr_final, delay_steps, delay_mult, max_steps = d[name + "_cfg"]
+    f = get_expon_lr_func(float(lr_init), float(lr_final), int(delay_steps), float(delay_mult), int(max_steps))
+    got = np.array([f(int(t)) for t in d["steps"]])
+    assert np.allclose(got, d[name], rtol=1e-12, atol=0.0)

@@ -129,3 +129,38 @@ def test_dropin_module_signature_and_errors():
         r(means3D=z, means2D=z, opacities=torch.zeros(2, 1), shs=torch.zeros(2, 1, 3), scales=z, rotations=torch.zeros(2, 4), cov3D_precomp=torch.zeros(2, 6))
     vis = r.markVisible(torch.tensor([[0.0, 0, 1.0], [0.0, 0, 0.1]]))
     assert vis.tolist() == [True, False]
+
+
+def test_model_schedule_and_sh_degree_surface():
+    """update_learning_rate / oneupSHdegree of the model mirror (scene/gaussian_model.py:121-123, 171-177): only the
+    group named "xyz" follows the schedule."""
+    from types import SimpleNamespace
+    from ggsplat.inner_step import DEFAULT_OPT
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    m = MeshGaussianModel(sh_degree=2)
+    m.optimizer = SimpleNamespace(param_groups=[{"name": "xyz", "lr": 1.0}, {"name": "f_dc", "lr": 0.5}])
+    from ggsplat.schedule import get_expon_lr_func
+    m.xyz_scheduler_args = get_expon_lr_func(DEFAULT_OPT.position_lr_init, DEFAULT_OPT.position_lr_final,
+                                             lr_delay_mult=DEFAULT_OPT.position_lr_delay_mult,
+                                             max_steps=DEFAULT_OPT.position_lr_max_steps)
+    lr0 = m.update_learning_rate(0)
+    assert lr0 == pytest.approx(DEFAULT_OPT.position_lr_init) and m.optimizer.param_groups[0]["lr"] == lr0
+    assert m.update_learning_rate(DEFAULT_OPT.position_lr_max_steps) == pytest.approx(DEFAULT_OPT.position_lr_final)
+    assert m.optimizer.param_groups[1]["lr"] == 0.5
+    assert m.active_sh_degree == 0
+    for _ in range(5):
+        m.oneupSHdegree()
+    assert m.active_sh_degree == m.max_sh_degree == 2
+
+
+def test_graph_optimiser_and_step_refuse_what_they_cannot_run():
+    """No CPU path in the product: GraphAdam needs GPU parameters; the graphed step needs a GraphAdam."""
+    import torch
+    from ggsplat.adam import GraphAdam
+    from ggsplat.inner_step import GraphedRegistrationStep
+    with pytest.raises(RuntimeError):
+        GraphAdam([{"params": [torch.zeros(4, requires_grad=True)], "lr": 1e-3}])
+    from types import SimpleNamespace
+    fake = SimpleNamespace(optimizer=object(), _xyz=torch.zeros(1, 3))
+    with pytest.raises(TypeError):
+        GraphedRegistrationStep(fake, 16, 16, torch.zeros(3))
