@@ -238,6 +238,23 @@ class MeshGaussianModel:
                     self.optimizer.push_lr()
                 return lr
 
+    def reset_opacity(self):
+        """scene/gaussian_model.py:212-215 (+ replace_tensor_to_optimizer :261-274): opacities are clamped to <= 0.01 and
+        the Adam moments of the opacity group start again from zero.  Done IN PLACE -- the reference swaps in a new
+        nn.Parameter, which would invalidate the pointers of a captured step."""
+        with torch.no_grad():
+            o = torch.clamp(self.get_opacity, max=0.01)
+            self._opacity.copy_(torch.log(o / (1.0 - o)))
+        st = getattr(self.optimizer, "state", {}).get(self._opacity) if self.optimizer is not None else None
+        if st:
+            for k in ("exp_avg", "exp_avg_sq"):
+                if k in st:
+                    st[k].zero_()
+
+    @property
+    def num_gs(self) -> int:
+        return self._xyz.shape[0]
+
     def oneupSHdegree(self):
         """scene/gaussian_model.py:121-123."""
         if self.active_sh_degree < self.max_sh_degree:

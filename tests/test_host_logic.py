@@ -164,3 +164,24 @@ def test_graph_optimiser_and_step_refuse_what_they_cannot_run():
     fake = SimpleNamespace(optimizer=object(), _xyz=torch.zeros(1, 3))
     with pytest.raises(TypeError):
         GraphedRegistrationStep(fake, 16, 16, torch.zeros(3))
+
+
+def test_reset_opacity_in_place():
+    """scene/gaussian_model.py:212-215: opacity clamped to <= 0.01, moments of that group zeroed; same tensor object."""
+    import torch
+    from types import SimpleNamespace
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    m = MeshGaussianModel(sh_degree=0)
+    m._xyz = torch.zeros(5, 3)
+    m._opacity = torch.tensor([[-6.0], [-4.0], [0.0], [2.0], [5.0]], requires_grad=True)
+    m.optimizer = torch.optim.Adam([{"params": [m._opacity], "lr": 0.05, "name": "opacity"}], lr=0.0, eps=1e-15)
+    m._opacity.grad = torch.ones_like(m._opacity)
+    m.optimizer.step()
+    ptr = m._opacity.data_ptr()
+    before = torch.sigmoid(m._opacity.detach()).clone()
+    m.reset_opacity()
+    after = torch.sigmoid(m._opacity.detach())
+    assert m._opacity.data_ptr() == ptr and m.num_gs == 5
+    assert torch.allclose(after, torch.clamp(before, max=0.01), rtol=1e-5, atol=1e-7)
+    st = m.optimizer.state[m._opacity]
+    assert float(st["exp_avg"].abs().max()) == 0.0 and float(st["exp_avg_sq"].abs().max()) == 0.0
