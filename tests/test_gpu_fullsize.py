@@ -1,5 +1,6 @@
-"""Full BASELINE size (100k mesh-bound Gaussians, 1920x1080, config 2) checked through size-independent
-properties, because the oracle cannot finish 1080p in test time:
+"""Full BASELINE size (100k mesh-bound Gaussians, 1920x1080, config 2): ONE view directly against the C oracle
+(OpenMP on the host cores: well under a second), and -- since the oracle cannot do the whole 160-view batch in test
+time -- size-independent properties:
   * partition of unity: all colours == background == c  =>  image == c everywhere  (sum alpha T + T_final = 1)
   * linearity in colour: render(a x + b y) == a render(x) + b render(y)   (bg = 0)
   * adjointness: <dL/dcolors, dc> == < w, render(dc) >  -- the colour backward is the transpose of the forward
@@ -126,3 +127,37 @@ def test_batch_equals_single_views_bitwise(scene):
         c1, r1, d1, a1, _ = _fwd(inp, ck, colors=col, bg=(0.1, 0.2, 0.3), views=slice(v, v + 1))
         assert torch.equal(c1[0], color[v]) and torch.equal(r1[0], radii[v])
         assert torch.equal(d1[0], depth[v]) and torch.equal(a1[0], alpha[v])
+
+
+def test_one_view_against_the_c_oracle(scene):
+    """The C oracle (OpenMP, all host cores) does finish ONE 1080p view of config 2 in well under a second on the GPU
+    box's host: image, depth, alpha, radii and every gradient of that view against the HIP path, at the north-star
+    tolerance."""
+    import numpy as np
+    from helpers import REL_L1_TOL, rel_l1
+    from oracle.c_oracle import COracle
+    from ggsplat import rasterizer as R
+    inp, ck = scene
+    P = inp["means3D"].shape[0]
+    g = torch.Generator().manual_seed(7)
+    colors = torch.rand(P, 3, generator=g)
+    w = torch.randn(3, H, W, generator=g)
+    vi = 1
+    cam = S.rig_cameras()[47]
+    color, radii, depth, alpha, st = _fwd(inp, ck, colors=colors.cuda(), keep=True, views=slice(vi, vi + 1))
+    gr = R.backward_views(st, w.cuda()[None], want_means2D=True)
+    ci = {k: v.cpu() for k, v in inp.items()}
+    co = COracle(means3D=ci["means3D"], opacities=ci["opacities"], colors_precomp=colors, scales=ci["scales"],
+                 rotations=ci["rotations"], viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+                 campos=cam.camera_center, bg=torch.zeros(3), W=W, H=H, tanfovx=math.tan(cam.FoVx * 0.5),
+                 tanfovy=math.tan(cam.FoVy * 0.5), sh_degree=0)
+    og = co.backward(w)
+    assert np.array_equal(radii[0].cpu().numpy(), co.radii)
+    assert rel_l1(color[0].cpu(), co.color) <= REL_L1_TOL
+    assert rel_l1(depth[0].cpu(), co.depth.reshape(H, W)) <= REL_L1_TOL
+    assert rel_l1(alpha[0].cpu(), co.alpha.reshape(H, W)) <= REL_L1_TOL
+    for k, ok in (("means3D", "means3D"), ("opacities", "opacities"), ("colors_precomp", "colors"), ("scales", "scales"),
+                  ("rotations", "rotations")):
+        assert rel_l1(gr[k].cpu().reshape(og[ok].shape), og[ok]) <= REL_L1_TOL, k
+    assert rel_l1(gr["means2D"][0].cpu().reshape(og["means2D"].shape), og["means2D"]) <= REL_L1_TOL
+    co.close()
