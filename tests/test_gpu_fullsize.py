@@ -161,3 +161,41 @@ def test_one_view_against_the_c_oracle(scene):
         assert rel_l1(gr[k].cpu().reshape(og[ok].shape), og[ok]) <= REL_L1_TOL, k
     assert rel_l1(gr["means2D"][0].cpu().reshape(og["means2D"].shape), og["means2D"]) <= REL_L1_TOL
     co.close()
+
+
+def test_stress_config_view_against_the_c_oracle():
+    """BASELINE config 5 (stress): ~500k Gaussians, 3840x2160, SH degree 3 -- one view against the C oracle."""
+    import numpy as np
+    from helpers import REL_L1_TOL, rel_l1
+    from oracle.c_oracle import COracle
+    from ggsplat import rasterizer as R
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    W4, H4 = 3840, 2160
+    v, f = S.skirt_mesh(559, 448)
+    params = S.skirt_gaussian_params(f.shape[0], sh_degree=3)
+    m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=3, device="cuda")
+    m.update_face_coor()
+    with torch.no_grad():
+        inp = dict(means3D=m.get_xyz.clone(), scales=m.get_scaling.clone(), rotations=m.get_rotation.clone(),
+                   opacities=m.get_opacity.clone(), shs=m.get_features.clone())
+    cam = S.rig_cameras(n_rings=1, n_az=4, width=W4, height=H4, f=3000.0)[1]
+    ck = S.stack_cameras([cam], device="cuda")
+    color, radii, depth, alpha, st = R.forward_views(
+        inp["means3D"], inp["opacities"], inp["shs"], None, inp["scales"], inp["rotations"], None, view=ck["view"],
+        proj=ck["proj"], campos=ck["campos"], tanfov=ck["tanfov"], bg=torch.zeros(3, device="cuda"), W=W4, H=H4,
+        sh_degree=3)
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(3, H4, W4, generator=g)
+    gr = R.backward_views(st, w.cuda()[None], want_means2D=False)
+    ci = {k: t.cpu() for k, t in inp.items()}
+    co = COracle(means3D=ci["means3D"], opacities=ci["opacities"], shs=ci["shs"], scales=ci["scales"],
+                 rotations=ci["rotations"], viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform,
+                 campos=cam.camera_center, bg=torch.zeros(3), W=W4, H=H4, tanfovx=math.tan(cam.FoVx * 0.5),
+                 tanfovy=math.tan(cam.FoVy * 0.5), sh_degree=3)
+    og = co.backward(w)
+    assert np.array_equal(radii[0].cpu().numpy(), co.radii)
+    assert rel_l1(color[0].cpu(), co.color) <= REL_L1_TOL
+    assert rel_l1(alpha[0].cpu(), co.alpha.reshape(H4, W4)) <= REL_L1_TOL
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        assert rel_l1(gr[k].cpu().reshape(og[k].shape), og[k]) <= REL_L1_TOL, k
+    co.close()
