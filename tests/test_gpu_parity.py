@@ -257,3 +257,22 @@ def test_random_sweep(P, W, H, deg, seed, scale_mul, boost, cam_index, bg):
     _compare(_add_precomp(sc), cam, list(bg), dict(sh=True, cov=False))
     if seed % 2 == 0:
         _compare(sc, cam, list(bg), dict(sh=False, cov=True, da=False))
+
+
+@pytest.mark.parametrize("cam_index,bg", [(0, (0.0, 0.0, 0.0)), (1, (0.7, 0.2, 0.4)), (2, (0.0, 0.0, 0.0)), (3, (0.1, 0.9, 0.5))])
+def test_config1_plumbing_case(cam_index, bg):
+    """BASELINE config 1 as specified: 10k random Gaussians, SH degree 3, 4 cameras on a radius-4 circle,
+    512x512, fx = fy = 600, principal point (250, 262), black and non-black backgrounds."""
+    sc = S_random(10_000)
+    cam = S_orbit()[cam_index]
+    _compare(_add_precomp(sc), cam, list(bg), dict(sh=True, cov=False))
+
+
+def S_random(P):
+    from ggsplat import synthetic as S
+    return S.random_gaussians(P, sh_degree=3, seed=0)
+
+
+def S_orbit():
+    from ggsplat import synthetic as S
+    return S.orbit_cameras(4)
