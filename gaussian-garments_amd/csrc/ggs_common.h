@@ -27,9 +27,9 @@
 // splat can reach / was blended in 8x8 quadrant q of the tile).  Limits P to 2^28.
 #define GGS_ID_BITS 28
 #define GGS_ID_MASK 0x0fffffffu
-#define GGS_NBUCKET 8             // list-length classes used to order the per-tile work items
+#define GGS_NBUCKET 16            // list-length classes used to order the per-tile work items
 #define GGS_BUCKET_COUNT_OFF 64   // byte offsets inside the header region
-#define GGS_BUCKET_CURSOR_OFF 96
+#define GGS_BUCKET_CURSOR_OFF 128
 
 // Constants of the algorithm, one line each.
 #define GGS_NEAR_Z 0.2f
@@ -109,23 +109,29 @@ __device__ __forceinline__ float ggs_max(float a, float b) { return a > b ? a : 
 // The per-tile kernels walk `order[]` (class 0 first): the longest serial chains start first and the
 // tail of every launch is made of short / empty tiles (LPT scheduling), instead of whatever the last
 // view happens to contain.
+// Half-octave classes from 64 splats up (class 0: >= 3072, 1: 2048.., 2: 1536.., 3: 1024.., 4: 768.., 5: 512.., ...,
+// 11: 64..95), 12: 32..63, 13: < 32, 15: empty.  With whole octaves a 1000-splat tile could start after a 520-splat one.
 __device__ __forceinline__ int ggs_len_bucket(uint32_t L) {
-    if (L == 0) return 7;
+    if (L == 0) return GGS_NBUCKET - 1;
     const int lg = 31 - __clz((int)L);
-    return lg <= 5 ? 6 : (lg >= 11 ? 0 : 11 - lg);
+    if (lg >= 12) return 0;
+    if (lg <= 4) return 13;
+    if (lg == 5) return 12;
+    const int half = (int)((L >> (lg - 1)) & 1u);          // second most significant bit
+    return 2 * (11 - lg) + (1 - half);
 }
 
 // Position in order[] of the r-th non-empty work item (longest first); mirrors ggs_k_order_tiles.
 struct NonEmptyItems {
     uint32_t n, stride;        // n non-empty items, at order[r * stride]
-    uint32_t n_long;           // the first n_long of them have >= 512 splats (classes 0..2)
+    uint32_t n_long;           // the first n_long of them have >= 1024 splats (classes 0..3)
 };
 __device__ __forceinline__ NonEmptyItems ggs_nonempty_items(const uint32_t* bucket_count, uint32_t n_items) {
     const uint32_t E = bucket_count[GGS_NBUCKET - 1];
     NonEmptyItems it;
     it.n = n_items - E;
     it.stride = (it.n ? (E / it.n) & ~1u : 0) + 1;
-    it.n_long = bucket_count[0] + bucket_count[1] + bucket_count[2];
+    it.n_long = bucket_count[0] + bucket_count[1] + bucket_count[2] + bucket_count[3];
     return it;
 }
 
