@@ -84,7 +84,7 @@ def main():
 
     from ggsplat import batch, synthetic as S
     from ggsplat import _lib
-    from ggsplat.dist import all_reduce_grads, shard_views
+    from ggsplat.dist import all_reduce_bucket, bucket_views, flatten_grads, shard_views
     from ggsplat.mesh_gaussian_model import MeshGaussianModel
     import ctypes as C
 
@@ -120,7 +120,9 @@ def main():
         torch.autograd.backward([xyz, scaling, rot, opacity, shs],
                                 [gr["means3D"], gr["scales"], gr["rotations"], gr["opacities"], gr["shs"]])
         stats["num_rendered"] = gr["num_rendered"]
-        return [p.grad if p.grad is not None else torch.zeros_like(p) for p in plist]
+        # the flat bucket [mesh.v | _xyz | f_dc | f_rest | opacity | scaling | rotation] is built here (one cat kernel,
+        # inside the captured graph); the step's all-reduce works on it directly and the per-tensor gradients are views
+        return flatten_grads([p.grad if p.grad is not None else torch.zeros_like(p) for p in plist])
 
     graph = {"g": None, "grads": None, "headers": []}
 
@@ -131,10 +133,11 @@ def main():
         # per launch set were ~7 % of it.
         if graph["g"] is not None:
             graph["g"].replay()
-            grads = graph["grads"]
+            flat = graph["grads"]
         else:
-            grads = compute()
-        all_reduce_grads(grads, n_views_total)
+            flat = compute()
+        all_reduce_bucket(flat)                   # ONE RCCL call per step, nothing else around it
+        stats["grads"] = bucket_views(flat, plist)
 
     def capture():
         from ggsplat import rasterizer as R

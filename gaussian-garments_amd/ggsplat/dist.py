@@ -33,16 +33,39 @@ def unflatten_into(flat: torch.Tensor, tensors: Sequence[torch.Tensor]) -> None:
         o += n
 
 
+def _distributed() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
 def all_reduce_grads(grads: Sequence[torch.Tensor], n_views_total: int = 0, average: bool = False) -> torch.Tensor:
     """Sum (optionally / n_views_total) the gradient tensors over all ranks, in place, through one flat bucket.
-    Returns the bucket (useful for tests).  No-op for world size 1 / uninitialised process group."""
+    Returns the bucket (useful for tests).  World size 1 without averaging: nothing to do, no copies."""
+    if not _distributed() and not (average and n_views_total > 0):
+        return flatten_grads(grads)
     flat = flatten_grads(grads)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _distributed():
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
     if average and n_views_total > 0:
         flat /= float(n_views_total)
     unflatten_into(flat, grads)
     return flat
+
+
+def bucket_views(flat: torch.Tensor, like: Sequence[torch.Tensor]) -> List[torch.Tensor]:
+    """Views into a flat bucket shaped like `like` (no copies): gradients that live in the bucket from the start need
+    neither the flatten nor the unflatten kernels around the collective."""
+    out, o = [], 0
+    for t in like:
+        n = t.numel()
+        out.append(flat[o:o + n].view(t.shape))
+        o += n
+    return out
+
+
+def all_reduce_bucket(flat: torch.Tensor) -> None:
+    """One all-reduce(sum) of a gradient bucket that is already flat (RCCL over xGMI; gloo in the CPU tests)."""
+    if _distributed():
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
 
 
 def all_reduce_densification_stats(xyz_gradient_accum: torch.Tensor, denom: torch.Tensor, max_radii2D: torch.Tensor):
