@@ -7,7 +7,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ggsplat.dist import all_reduce_densification_stats, all_reduce_grads, flatten_grads, shard_views, unflatten_into
+from ggsplat.dist import (all_reduce_bucket, all_reduce_densification_stats, all_reduce_grads, bucket_views,
+                          flatten_grads, shard_views, unflatten_into)
 
 
 def test_shard_views_partition():
@@ -47,7 +48,13 @@ def _worker(rank, world, port, q):
         g = torch.Generator().manual_seed(100 + v)
         for t in grads:
             t += torch.randn(t.shape, generator=g)
+    # the same exchange with the gradients living in the bucket from the start (what bench.py's captured step does)
+    bucket = flatten_grads(grads)
+    views = bucket_views(bucket, grads)
+    all_reduce_bucket(bucket)
     flat = all_reduce_grads(grads, n_views_total=10, average=True)
+    assert all(torch.allclose(v / 10.0, g, rtol=1e-6, atol=1e-7) for v, g in zip(views, grads))
+    assert all(v.data_ptr() >= bucket.data_ptr() and v.shape == g.shape for v, g in zip(views, grads))
     acc, den, rad = torch.full((6, 1), float(rank + 1)), torch.ones(6, 1), torch.tensor([1.0 + rank, 5.0 - rank])
     all_reduce_densification_stats(acc, den, rad)
     q.put((rank, [t.clone() for t in grads], flat.numel(), acc.clone(), den.clone(), rad.clone()))
