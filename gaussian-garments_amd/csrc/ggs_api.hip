@@ -3,6 +3,7 @@
 // stream.  No allocation, no synchronisation (unless GgsParams.debug), no exceptions.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "ggs_kernels.h"
@@ -112,7 +113,16 @@ int bwd_splits(const GgsParams* p) {
 }
 
 // launches with fewer (view, tile) work items than this use the one-wave-per-quadrant render kernels
-#define GGS_QUAD_ITEMS 24576
+#define GGS_QUAD_ITEMS_DEFAULT 57344       // measured crossover at config 2: ~7 views of 8160 tiles (tools/dbg/quad_threshold.py)
+// (tuning knob: the environment variable GGS_QUAD_ITEMS overrides the threshold; read once)
+static int quad_items() {
+    static const int v = [] {
+        const char* e = getenv("GGS_QUAD_ITEMS");
+        return e && *e ? atoi(e) : GGS_QUAD_ITEMS_DEFAULT;
+    }();
+    return v;
+}
+#define GGS_QUAD_ITEMS quad_items()
 
 struct Dims { int gx, gy, T; };
 Dims dims(const GgsParams* p) {
