@@ -14,8 +14,22 @@ namespace {
 
 struct AdamState { long long step; float bias1; float bias2_sqrt; double pow1; double pow2; };   // 32 bytes, device
 
+struct TickMulti { int n; AdamState* s[16]; };
+
+__device__ __forceinline__ void adam_tick_one(AdamState* s, double beta1, double beta2);
+
 __global__ void k_adam_tick(AdamState* s, double beta1, double beta2, const unsigned long long* guard) {
     if (guard && *guard) return;
+    adam_tick_one(s, beta1, beta2);
+}
+// one thread per tensor: torch keeps a step count PER PARAMETER (a parameter without gradient skips the step and its
+// bias corrections lag behind), so every tensor has its own state
+__global__ void k_adam_tick_multi(TickMulti m, double beta1, double beta2, const unsigned long long* guard) {
+    if (guard && *guard) return;
+    if ((int)threadIdx.x < m.n) adam_tick_one(m.s[threadIdx.x], beta1, beta2);
+}
+
+__device__ __forceinline__ void adam_tick_one(AdamState* s, double beta1, double beta2) {
     const long long t = s->step + 1;
     s->step = t;
     // beta^t as a running double product (torch evaluates beta ** step in Python floats each step; the products agree to
@@ -78,7 +92,7 @@ struct AdamMulti {
     float* p[GGS_ADAM_MAX_TENSORS]; const float* g[GGS_ADAM_MAX_TENSORS];
     float* m[GGS_ADAM_MAX_TENSORS]; float* v[GGS_ADAM_MAX_TENSORS];
     const float* lr[GGS_ADAM_MAX_TENSORS];
-    const AdamState* s; const unsigned long long* guard;
+    const AdamState* s[GGS_ADAM_MAX_TENSORS]; const unsigned long long* guard;
     float beta1, beta2, omb1, omb2, eps;
 };
 
@@ -89,7 +103,7 @@ __global__ __launch_bounds__(256) void k_adam_multi(AdamMulti mt) {
     AdamArgs a;
     a.n = mt.numel[t]; a.p = mt.p[t]; a.g = mt.g[t]; a.m = mt.m[t]; a.v = mt.v[t];
     a.beta1 = mt.beta1; a.beta2 = mt.beta2; a.omb1 = mt.omb1; a.omb2 = mt.omb2; a.eps = mt.eps;
-    const float step_size = *mt.lr[t] / mt.s->bias1, bs = mt.s->bias2_sqrt;
+    const float step_size = *mt.lr[t] / mt.s[t]->bias1, bs = mt.s[t]->bias2_sqrt;
     const unsigned b0 = mt.first_block[t], nb = mt.first_block[t + 1] - b0;
     const size_t n4 = a.n / 4, stride = (size_t)nb * 256;
     float4* p4 = reinterpret_cast<float4*>(a.p);
@@ -148,31 +162,50 @@ int ggs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, flo
     return GGS_OK;
 }
 
+int ggs_adam_tick_multi(int n_states, void* const* states, double beta1, double beta2, const void* guard, void* stream) {
+    ggs_clear_error_();
+    if (n_states <= 0) return GGS_OK;
+    if (n_states > 16) return ggs_fail_(GGS_ERR_SIZE, "ggs_adam_tick_multi: at most 16 states per call");
+    if (!states) return ggs_fail_(GGS_ERR_ARG, "ggs_adam_tick_multi: NULL states");
+    TickMulti m;
+    m.n = n_states;
+    for (int i = 0; i < n_states; ++i) {
+        if (!states[i]) return ggs_fail_(GGS_ERR_ARG, "ggs_adam_tick_multi: NULL state");
+        m.s[i] = static_cast<AdamState*>(states[i]);
+    }
+    hipLaunchKernelGGL(k_adam_tick_multi, dim3(1), dim3(64), 0, (hipStream_t)stream, m, beta1, beta2,
+                       static_cast<const unsigned long long*>(guard));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "adam_tick_multi launch failed: %s", hipGetErrorString(e));
+    return GGS_OK;
+}
+
 int ggs_adam_step_multi(int n_tensors, const size_t* numel, float* const* params, const float* const* grads,
-                        float* const* exp_avgs, float* const* exp_avg_sqs, const float* const* lrs, double beta1,
-                        double beta2, double eps, const void* state, const void* guard, void* stream) {
+                        float* const* exp_avgs, float* const* exp_avg_sqs, const float* const* lrs,
+                        const void* const* states, double beta1, double beta2, double eps, const void* guard,
+                        void* stream) {
     ggs_clear_error_();
     if (n_tensors <= 0) return GGS_OK;
     if (n_tensors > GGS_ADAM_MAX_TENSORS) return ggs_fail_(GGS_ERR_SIZE, "ggs_adam_step_multi: at most %d tensors per call", GGS_ADAM_MAX_TENSORS);
-    if (!numel || !params || !grads || !exp_avgs || !exp_avg_sqs || !lrs || !state)
+    if (!numel || !params || !grads || !exp_avgs || !exp_avg_sqs || !lrs || !states)
         return ggs_fail_(GGS_ERR_ARG, "ggs_adam_step_multi: NULL pointer argument");
     AdamMulti mt;
     mt.n = 0; mt.first_block[0] = 0;
     for (int t = 0; t < n_tensors; ++t) {
         if (numel[t] == 0) continue;
-        if (!params[t] || !grads[t] || !exp_avgs[t] || !exp_avg_sqs[t] || !lrs[t])
+        if (!params[t] || !grads[t] || !exp_avgs[t] || !exp_avg_sqs[t] || !lrs[t] || !states[t])
             return ggs_fail_(GGS_ERR_ARG, "ggs_adam_step_multi: NULL tensor pointer");
         if (!aligned16(params[t]) || !aligned16(grads[t]) || !aligned16(exp_avgs[t]) || !aligned16(exp_avg_sqs[t]))
             return ggs_fail_(GGS_ERR_ARG, "ggs_adam_step_multi: tensors must be 16-byte aligned");
         const int k = mt.n++;
         mt.numel[k] = numel[t]; mt.p[k] = params[t]; mt.g[k] = grads[t]; mt.m[k] = exp_avgs[t]; mt.v[k] = exp_avg_sqs[t];
-        mt.lr[k] = lrs[t];
+        mt.lr[k] = lrs[t]; mt.s[k] = static_cast<const AdamState*>(states[t]);
         size_t blocks = (numel[t] / 4 + 255) / 256;
         blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
         mt.first_block[k + 1] = mt.first_block[k] + (unsigned)blocks;
     }
     if (mt.n == 0) return GGS_OK;
-    mt.s = static_cast<const AdamState*>(state); mt.guard = static_cast<const unsigned long long*>(guard);
+    mt.guard = static_cast<const unsigned long long*>(guard);
     mt.beta1 = (float)beta1; mt.beta2 = (float)beta2; mt.omb1 = (float)(1.0 - beta1); mt.omb2 = (float)(1.0 - beta2);
     mt.eps = (float)eps;
     hipLaunchKernelGGL(k_adam_multi, dim3(mt.first_block[mt.n]), dim3(256), 0, (hipStream_t)stream, mt);

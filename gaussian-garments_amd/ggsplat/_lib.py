@@ -49,7 +49,8 @@ _SIGS = {
     "ggs_adam_state_bytes": (C.c_size_t, []),
     "ggs_adam_tick": (C.c_int, [_PTR, C.c_double, C.c_double, _PTR, _PTR]),
     "ggs_adam_step": (C.c_int, [C.c_size_t, _PTR, _PTR, _PTR, _PTR, _PTR, C.c_double, C.c_double, C.c_double, _PTR, _PTR, _PTR]),
-    "ggs_adam_step_multi": (C.c_int, [C.c_int] + [_PTR] * 6 + [C.c_double] * 3 + [_PTR] * 3),
+    "ggs_adam_tick_multi": (C.c_int, [C.c_int, _PTR, C.c_double, C.c_double, _PTR, _PTR]),
+    "ggs_adam_step_multi": (C.c_int, [C.c_int] + [_PTR] * 7 + [C.c_double] * 3 + [_PTR] * 2),
     "ggs_registration_aux": (C.c_int, [C.c_int] + [_PTR] * 7 + [C.c_float] * 4 + [_PTR] * 9),
     "ggs_visibility_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_size_t]),
     "ggs_visibility": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 6 + [C.c_size_t, _PTR, _PTR, _PTR]),

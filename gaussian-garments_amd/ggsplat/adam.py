@@ -37,7 +37,7 @@ class GraphAdam:
             raise RuntimeError("ggsplat GraphAdam runs on the GPU only (no CPU path in the product)")
         dev = self.device = first.device
         L = lib()
-        self._state = torch.zeros(int(L.ggs_adam_state_bytes()), dtype=torch.uint8, device=dev)
+        self._state_bytes = int(L.ggs_adam_state_bytes())
         self._lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
         self._lr_host = torch.zeros(len(self.param_groups), dtype=torch.float32).pin_memory()
         self.state: Dict[torch.Tensor, Dict[str, torch.Tensor]] = {}
@@ -45,7 +45,9 @@ class GraphAdam:
             for p in g["params"]:
                 if p.dtype != torch.float32 or not p.is_contiguous():
                     raise ValueError("GraphAdam: parameters must be contiguous float32 tensors")
-                self.state[p] = {"exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
+                self.state[p] = {"exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p),
+                                 # step count + bias corrections of THIS parameter (torch counts steps per parameter)
+                                 "state": torch.zeros(self._state_bytes, dtype=torch.uint8, device=dev)}
         self.push_lr()
 
     # ---- learning rates ---------------------------------------------------------------------------------
@@ -57,7 +59,8 @@ class GraphAdam:
 
     @property
     def step_count(self) -> int:
-        return int(self._state[:8].view(torch.int64).item())
+        """Steps taken by the most-stepped parameter."""
+        return max((int(st["state"][:8].view(torch.int64).item()) for st in self.state.values()), default=0)
 
     # ---- torch.optim.Optimizer surface ------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = True) -> None:
@@ -77,8 +80,7 @@ class GraphAdam:
             raise ValueError("GraphAdam.step: guard must be a 64-bit word on the optimiser's device")
         gp = ptr(guard)
         b1, b2 = self.betas
-        check(L.ggs_adam_tick(ptr(self._state), b1, b2, gp, stream), "ggs_adam_tick")
-        # every tensor that has a gradient, in one launch (ggs_adam_step_multi takes up to 16 per call)
+        # every tensor that has a gradient: one tick launch (step counts / bias corrections) and one update launch per 16
         items = []
         for i, g in enumerate(self.param_groups):
             for p in g["params"]:
@@ -87,11 +89,12 @@ class GraphAdam:
                 grad = p.grad if (p.grad.is_contiguous() and p.grad.dtype == torch.float32) else p.grad.float().contiguous()
                 st = self.state[p]
                 items.append((p.numel(), p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(),
-                              st["exp_avg_sq"].data_ptr(), self._lr_dev.data_ptr() + 4 * i, grad))
+                              st["exp_avg_sq"].data_ptr(), self._lr_dev.data_ptr() + 4 * i, st["state"].data_ptr(), grad))
         for k in range(0, len(items), 16):
             chunk = items[k:k + 16]
             n = len(chunk)
             numel = (C.c_size_t * n)(*[c[0] for c in chunk])
-            cols = [(C.c_void_p * n)(*[c[j] for c in chunk]) for j in range(1, 6)]
-            check(L.ggs_adam_step_multi(n, numel, cols[0], cols[1], cols[2], cols[3], cols[4], b1, b2, self.eps,
-                                        ptr(self._state), gp, stream), "ggs_adam_step_multi")
+            cols = [(C.c_void_p * n)(*[c[j] for c in chunk]) for j in range(1, 7)]
+            check(L.ggs_adam_tick_multi(n, cols[5], b1, b2, gp, stream), "ggs_adam_tick_multi")
+            check(L.ggs_adam_step_multi(n, numel, cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], b1, b2,
+                                        self.eps, gp, stream), "ggs_adam_step_multi")

@@ -218,11 +218,14 @@ size_t ggs_adam_state_bytes(void);
 int ggs_adam_tick(void* state, double beta1, double beta2, const void* guard, void* stream);
 int ggs_adam_step(size_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const float* lr,
                   double beta1, double beta2, double eps, const void* state, const void* guard, void* stream);
-/* The same update for up to 16 tensors in ONE launch (host arrays of n_tensors sizes / device pointers; lrs[t] points at
- * the device float holding tensor t's learning rate).  Empty tensors are skipped. */
+/* The same for up to 16 tensors per launch.  torch keeps a step count per PARAMETER (one without gradient skips the step and
+ * its bias corrections lag), so every tensor has its own `state`: states[t], lrs[t] (device float), host arrays of
+ * n device pointers / sizes.  Empty tensors are skipped. */
+int ggs_adam_tick_multi(int n_states, void* const* states, double beta1, double beta2, const void* guard, void* stream);
 int ggs_adam_step_multi(int n_tensors, const size_t* numel, float* const* params, const float* const* grads,
-                        float* const* exp_avgs, float* const* exp_avg_sqs, const float* const* lrs, double beta1,
-                        double beta2, double eps, const void* state, const void* guard, void* stream);
+                        float* const* exp_avgs, float* const* exp_avg_sqs, const float* const* lrs,
+                        const void* const* states, double beta1, double beta2, double eps, const void* guard,
+                        void* stream);
 
 /*
  * The rest of one s2 registration iteration in two kernels: hinge regularisers of the first-frame

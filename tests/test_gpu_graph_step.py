@@ -153,3 +153,26 @@ def test_graphed_mesh_only_step_without_mask(lean):
     assert float((a - torch.as_tensor(v, device="cuda")).abs().max()) > 0      # the vertices did move
     assert torch.equal(graphed._xyz.detach(), eager._xyz.detach())              # nothing else was touched
     assert float(graphed.denom.abs().max()) == 0.0
+
+
+def test_graph_adam_many_tensors_and_odd_sizes():
+    """More than 16 tensors (ggs_adam_step_multi takes 16 per call), sizes that are not multiples of 4, an empty tensor
+    and a tensor without gradient (skipped like torch does)."""
+    from ggsplat.adam import GraphAdam
+    g = torch.Generator().manual_seed(5)
+    sizes = [1, 2, 3, 5, 7, 64, 255, 257, 1000, 1023, 4096, 33, 0, 9, 17, 31, 63, 65, 127, 129, 511]
+    a = [torch.randn(n, generator=g).cuda().requires_grad_(True) for n in sizes]
+    b = [t.detach().clone().requires_grad_(True) for t in a]
+    ref = torch.optim.Adam([{"params": [p], "lr": 1e-3 * (i + 1)} for i, p in enumerate(b)], lr=0.0, eps=1e-15)
+    opt = GraphAdam([{"params": [p], "lr": 1e-3 * (i + 1)} for i, p in enumerate(a)], lr=0.0, eps=1e-15)
+    for it in range(3):
+        for i, (pa, pb) in enumerate(zip(a, b)):
+            if i == 5 and it == 1:
+                pa.grad, pb.grad = None, None             # no gradient this step
+                continue
+            gr = torch.randn(pa.shape, generator=g).cuda()
+            pa.grad, pb.grad = gr.clone(), gr.clone()
+        ref.step()
+        opt.step()
+    for pa, pb in zip(a, b):
+        assert torch.allclose(pa, pb, rtol=2e-6, atol=1e-7)
