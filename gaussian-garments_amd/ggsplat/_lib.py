@@ -91,4 +91,4 @@ def ptr(t):
     if t is None:
         return None
     assert t.is_contiguous(), "ggsplat: tensor must be contiguous"
-    return C.c_void_p(t.data_ptr())
+    return t.data_ptr()             # ctypes converts the int for the void* parameters (no c_void_p object per argument)

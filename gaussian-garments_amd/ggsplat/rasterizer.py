@@ -52,11 +52,27 @@ def grow_capacity(factor: float = 2.0) -> None:
 
 
 def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
-    if t is None:
-        return None
+    if t is None or (t.dtype is torch.float32 and t.is_contiguous()):      # the common case costs two attribute reads
+        return t
     if t.dtype != torch.float32:
         t = t.float()
     return t.contiguous()
+
+
+_ws_sizes: Dict[Tuple, Tuple[int, int, int]] = {}
+
+
+def _workspace_sizes(L, prm, cap: int) -> Tuple[int, int, int]:
+    """ggs_workspace_sizes, memoised per problem shape (the per-view loop asks the same question every call)."""
+    k = (prm.P, prm.K, prm.W, prm.H, prm.n_views, cap)
+    r = _ws_sizes.get(k)
+    if r is None:
+        gsz, isz, bsz = C.c_size_t(), C.c_size_t(), C.c_size_t()
+        check(L.ggs_workspace_sizes(C.byref(prm), cap, C.byref(gsz), C.byref(isz), C.byref(bsz)), "ggs_workspace_sizes")
+        if len(_ws_sizes) > 256:
+            _ws_sizes.clear()
+        r = _ws_sizes[k] = (gsz.value, isz.value, bsz.value)
+    return r
 
 
 _pinned: Dict = {}
@@ -112,8 +128,13 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
     proj = _f32c(proj).reshape(V, 16)
     campos = _f32c(campos).reshape(V, 3)
     tanfov = _f32c(tanfov).reshape(V, 2)
-    bg = _f32c(bg).to(dev)
-    bg = bg.reshape(1, 3).expand(V, 3).contiguous() if bg.numel() == 3 else bg.reshape(V, 3).contiguous()
+    bg = _f32c(bg)
+    if bg.device != dev:
+        bg = bg.to(dev)
+    if bg.numel() == 3:
+        bg = bg.reshape(1, 3) if V == 1 else bg.reshape(1, 3).expand(V, 3).contiguous()
+    else:
+        bg = bg.reshape(V, 3).contiguous()
     K = shs.shape[1] if shs is not None else 0
     prm = GgsParams(P, K, int(sh_degree), int(W), int(H), V, float(scale_modifier), 0, int(bool(debug)))
 
@@ -125,7 +146,8 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
     global _last_header
     key = (dev.index, P, W, H, V)
     cap = _cap_hint.get(key, max(8 * P * V, 1 << 16))
-    stream = _stream_ptr(dev)
+    cur_stream = torch.cuda.current_stream(dev)
+    stream = C.c_void_p(cur_stream.cuda_stream)
     host = _pinned_header(dev)
     geom = img = None
     capturing = torch.cuda.is_current_stream_capturing()
@@ -133,11 +155,10 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
         if key not in _cap_hint:
             raise _lib.GgsError("ggsplat: run this configuration eagerly once before capturing it into a graph "
                                 "(the binning capacity is learnt from an eager call)")
-        gsz, isz, bsz = C.c_size_t(), C.c_size_t(), C.c_size_t()
-        check(L.ggs_workspace_sizes(C.byref(prm), cap, C.byref(gsz), C.byref(isz), C.byref(bsz)), "ggs_workspace_sizes")
-        geom = torch.empty(gsz.value, device=dev, dtype=torch.uint8)
-        img = torch.empty(isz.value, device=dev, dtype=torch.uint8)
-        binb = torch.empty(bsz.value, device=dev, dtype=torch.uint8)
+        gsz, isz, bsz = _workspace_sizes(L, prm, cap)
+        geom = torch.empty(gsz, device=dev, dtype=torch.uint8)
+        img = torch.empty(isz, device=dev, dtype=torch.uint8)
+        binb = torch.empty(bsz, device=dev, dtype=torch.uint8)
         args = (C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales),
                 ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov), ptr(geom),
                 ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha), ptr(radii), stream)
@@ -145,12 +166,11 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
         n = -1
         break
     while not capturing:
-        gsz, isz, bsz = C.c_size_t(), C.c_size_t(), C.c_size_t()
-        check(L.ggs_workspace_sizes(C.byref(prm), cap, C.byref(gsz), C.byref(isz), C.byref(bsz)), "ggs_workspace_sizes")
+        gsz, isz, bsz = _workspace_sizes(L, prm, cap)
         if geom is None:
-            geom = torch.empty(gsz.value, device=dev, dtype=torch.uint8)
-            img = torch.empty(isz.value, device=dev, dtype=torch.uint8)
-        binb = torch.empty(bsz.value, device=dev, dtype=torch.uint8)
+            geom = torch.empty(gsz, device=dev, dtype=torch.uint8)
+            img = torch.empty(isz, device=dev, dtype=torch.uint8)
+        binb = torch.empty(bsz, device=dev, dtype=torch.uint8)
         args = (C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales),
                 ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov), ptr(geom),
                 ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha), ptr(radii), stream)
@@ -158,7 +178,7 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
         # of GPU work (the upstream extension syncs at the same point to size its binning buffer).
         check(L.ggs_forward_count(*args), "ggs_forward_count")
         host.copy_(binb[:16].view(torch.int64), non_blocking=True)
-        torch.cuda.current_stream(dev).synchronize()
+        cur_stream.synchronize()
         n, overflow = int(host[0]), int(host[1])
         if not overflow:
             break
