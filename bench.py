@@ -250,7 +250,11 @@ def main():
                     "launch_views": chunk, "launch_ms": round(group_ms[dom], 4),
                     "alg_bytes_per_launch": int(dom_bytes),
                     "kernel_ms_per_launch": {k: round(v, 4) for k, v in kern_ms.items()},
+                    # B_ref: the same lower bound with the reference algorithm's global radix sort of 64-bit
+                    # (tile | depth) keys in place of the per-tile sort: N (12 + 24 ceil((32 + ceil(log2 T)) / 8))
                     "whole_path": {"alg_bytes_per_view": int(B_view),
+                                   "ref_alg_bytes_per_view": int(B_view - 36 * N_view + N_view * (
+                                       12 + 24 * math.ceil((32 + math.ceil(math.log2(max(T, 2)))) / 8))),
                                    "achieved_GBs": round(B_view * views_per_sec / 1e9, 2),
                                    "frac": round(B_view * views_per_sec / 1e9 / HBM_PEAK_GBS, 5)}}
 
