@@ -21,13 +21,19 @@ __global__ __launch_bounds__(1024) void ggs_k_scan_tiles(ScanArgs a) {
     __shared__ uint32_t s_bucket[GGS_NBUCKET];
     if (tid < GGS_NBUCKET) s_bucket[tid] = 0;
     __syncthreads();
-    uint32_t local = 0;
+    // ~90 % of the tiles of an image are empty: counted in a register and added once per wave -- as per-tile LDS
+    // atomics on the one "empty" counter they serialised (8160 same-address atomics = most of this kernel's 15 us)
+    uint32_t local = 0, n_empty = 0;
     for (int i = 0; i < per; ++i)
         if (t0 + i < a.T) {
             const uint32_t c = cnt[t0 + i];
             local += c;
-            atomicAdd(&s_bucket[ggs_len_bucket(c)], 1u);
+            if (c == 0) ++n_empty;
+            else atomicAdd(&s_bucket[ggs_len_bucket(c)], 1u);
         }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) n_empty += __shfl_xor(n_empty, d);
+    if ((tid & 63) == 0 && n_empty) atomicAdd(&s_bucket[GGS_NBUCKET - 1], n_empty);
     // inclusive scan inside each wave64, then across the 16 waves
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t x = local;
