@@ -99,7 +99,10 @@ def appearance_step(gaussians, net: Callable, viewpoint_cam, gt_image, mask, bg,
     loss.backward()
     if optimizer is not None:
         with torch.no_grad():
-            optimizer.step()
+            if isinstance(optimizer, GraphAdam):
+                optimizer.step(guard=R.last_header()[1:2])      # void when this step's forward overflowed (replay)
+            else:
+                optimizer.step()
             optimizer.zero_grad()
     loss_dict["loss"] = loss.detach()
     loss_dict["render_pkg"] = pkg
@@ -151,6 +154,7 @@ class GraphedRegistrationStep:
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out: Dict[str, torch.Tensor] = {}
         self.recaptures = 0
+        self.optimizer = gaussians.optimizer
         self._slack = float(capacity_slack)     # applied once to the learnt capacity (< 1 exercises the recovery path)
 
     def _load(self, cam, gt_image, mask):
@@ -247,7 +251,7 @@ class GraphedRegistrationStep:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self._body(optimizer_step=False, track=False)
-            g.optimizer.zero_grad()
+            self.optimizer.zero_grad()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         if self._slack != 1.0:
@@ -279,3 +283,37 @@ class GraphedRegistrationStep:
             self.recaptures += 1
             self.graph = None
             self._capture()
+
+
+class GraphedAppearanceStep(GraphedRegistrationStep):
+    """The s3 inner iteration (appearance_step above: net -> offsets -> render(vis_mask) -> five-term loss -> backward ->
+    Adam over the net's and the Gaussians' parameters) captured into a hipGraph and replayed per iteration.
+
+    `net(gaussians, cam)` must be capturable: static shapes, no host syncs (the StyleUNet on PyTorch-ROCm is; an open3d
+    ray cast is not -- `ggsplat.mesh_gaussian_model.visible_mask` is the GPU replacement).  The visibility mask is applied
+    to the opacities (`pipe.mask_by_opacity`) instead of gathering the visible Gaussians: same image, same gradients,
+    static shapes.  `optimizer` is a GraphAdam over whatever the step trains."""
+
+    def __init__(self, gaussians, net: Callable, W: int, H: int, bg, optimizer: GraphAdam, opt=DEFAULT_OPT,
+                 pipe=DEFAULT_PIPE, use_mask: bool = True, capacity_slack: float = 1.0):
+        if not isinstance(optimizer, GraphAdam):
+            raise TypeError("GraphedAppearanceStep needs a ggsplat.adam.GraphAdam")
+        saved = gaussians.optimizer
+        gaussians.optimizer = optimizer                      # the base constructor checks / records gaussians.optimizer
+        try:
+            super().__init__(gaussians, W, H, bg, opt=opt, pipe=SimpleNamespace(**{**vars(pipe), "mask_by_opacity": True}),
+                             first_frame_template=False, track_densification=False, use_mask=use_mask,
+                             capacity_slack=capacity_slack, lean=False)
+        finally:
+            gaussians.optimizer = saved
+        self.net = net
+        self.optimizer = optimizer
+
+    def _body(self, optimizer_step: bool, track: bool):
+        d = appearance_step(self.g, self.net, self.cam, self.gt, self.mask, self.bg,
+                            optimizer=self.optimizer if optimizer_step else None, opt=self.opt, pipe=self.pipe,
+                            fused_loss=True)
+        d.pop("render_pkg", None)
+        if not optimizer_step:
+            self.optimizer.zero_grad()
+        return d

@@ -74,6 +74,12 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
     else:
         colors_precomp = override_color
 
+    mask_radii = None
+    if vis_mask is not None and getattr(pipe, "mask_by_opacity", False):
+        # Same image and gradients as the gather below (a zero-opacity splat is culled before binning), but every shape
+        # stays static, which a captured hipGraph needs -- the boolean gather has a data-dependent length.
+        opacity = opacity * vis_mask.to(opacity.dtype).reshape(-1, 1)
+        mask_radii, vis_mask = vis_mask, None
     if vis_mask is not None:                    # only render visible Gaussians (s3)
         means3D, means2D, shs = _sel(means3D, vis_mask), _sel(means2D, vis_mask), _sel(shs, vis_mask)
         colors_precomp, opacity = _sel(colors_precomp, vis_mask), _sel(opacity, vis_mask)
@@ -84,6 +90,8 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
         scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
 
+    if mask_radii is not None:
+        radii = radii * mask_radii.to(radii.dtype)
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
             "radii": radii, "3dposition": means3D, "depth": depth, "alpha": alpha}
 
