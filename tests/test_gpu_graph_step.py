@@ -201,7 +201,13 @@ def test_graphed_appearance_step_matches_eager_gather_semantics():
             self.sh_off = torch.nn.Parameter((torch.randn(P, 1, 3, generator=gg) * 0.05).cuda())
 
         def forward(self, gaussians, cam):
-            return self.xyz_off, self.sh_off, vis
+            # the GPU ray cast (ggs_visibility) in place of the reference's open3d scene: no host round trip, so it
+            # can live inside the captured step; AND-ed with a fixed random mask to get a ~40 % visible set
+            from ggsplat.mesh_gaussian_model import visible_mask
+            with torch.no_grad():
+                seen = visible_mask(gaussians.mesh.v, gaussians.mesh.f, gaussians.binding,
+                                    gaussians.get_anchor_points(), cam.camera_center)
+            return self.xyz_off, self.sh_off, vis & seen
 
     sides = []
     for graph in (False, True):
