@@ -36,8 +36,8 @@ KERNELS = ["preprocess", "scan_tiles", "scatter", "sort_tiles", "render_fwd", "r
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed steps (default: ~2.5 s timed region at N=1)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--views", type=int, default=160)
     ap.add_argument("--sh-degree", type=int, default=0)
     ap.add_argument("--chunk", type=int, default=32, help="views per launch set")
@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every step eagerly instead of replaying the captured hipGraph of its compute part")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for functional tests)")
+    ap.add_argument("--dump-grads", default="", help="rank 0 saves the step's (all-reduced) flat gradient bucket to this .pt file")
     ap.add_argument("--single-device", action="store_true",
                     help="functional test only: every rank uses cuda:0 (needs --backend gloo)")
     return ap.parse_args()
@@ -67,10 +68,30 @@ def alg_bytes(P, K, P_vis, N, HW, T):
     }
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: re-run this file under torch.distributed.run, one rank per
+    GPU (rendezvous on 127.0.0.1, a free port), and pass the ranks' output through.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.single_device:
         local_rank = 0
@@ -189,6 +210,13 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     views_per_sec = n_views_total * args.steps / dt
+    ranks_seen = [{"rank": rank, "device": torch.cuda.get_device_name(dev), "index": dev.index, "views": len(my)}]
+    if world > 1:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, ranks_seen[0])
+        ranks_seen = gathered
+    if args.dump_grads and rank == 0:
+        torch.save(torch.cat([g.reshape(-1) for g in stats["grads"]]).cpu(), args.dump_grads)
 
     out = None
     if rank == 0:
@@ -349,6 +377,8 @@ def main():
             "config": {"workload": f"{Fn} mesh-bound Gaussians (skirt tube, MeshGaussianModel), {len(all_cams)} synthetic "
                                    f"{W}x{H} cameras, SH degree {args.sh_degree}, fwd+bwd with dense dL/dimage",
                        "views_per_step": n_views_total, "views_per_launch": chunk, "parallelism": f"views sharded x{world}",
+                       "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
+                       "ranks": ranks_seen,
                        "num_rendered_per_view": round(N_view, 1), "visible_per_view": round(P_vis, 1),
                        "mean_list_length_per_pixel": round(N_view / T, 2),
                        "mean_last_contributor_per_pixel": round(mean_contrib, 2)},
