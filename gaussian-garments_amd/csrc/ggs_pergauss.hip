@@ -517,7 +517,11 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a) {
                 accs += dM * R[j * 3 + k];
                 dR[j * 3 + k] = sv[k] * dM;
             }
-            ds[k] = a.scale_modifier * accs;
+            // Upstream's computeCov3D backward differentiates M = S R with S = diag(modifier * scale) and returns
+            // dL/dS_kk as dL/dscale_k: the chain-rule factor `modifier` is NOT applied there.  The bar is "results
+            // identical to the reference's", so neither is it here (exact derivative = modifier * accs; s2 / s3 always
+            // pass modifier = 1, gaussian_renderer/__init__.py:46).
+            ds[k] = accs;
         }
         const float r = q[0], x = q[1], y = q[2], z = q[3];
         const float dq0 = 2.f * (-z * dR[1] + y * dR[2] + z * dR[3] - x * dR[5] - y * dR[6] + x * dR[7]);

@@ -129,13 +129,16 @@ namespace {
 // Same arithmetic per pixel, bit-identical results.
 __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
     constexpr int NQ = 4, q0 = 0;
-    if (a.header->overflow) return;
+    // A forward that overflowed its binning capacity (only possible with a static capacity inside a captured graph) has no
+    // lists: every tile is composited as EMPTY, so the outputs are deterministic (background, zero depth / alpha,
+    // final_T = 1, n_contrib = 0) instead of uninitialised memory.  The overflow word tells the caller to re-run.
+    const bool overflow = a.header->overflow != 0;
     const uint32_t item = a.order[blockIdx.x];   // work items, longest lists first
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
     const int tx = t % a.gx, ty = t / a.gx;
     const int ox = tx * GGS_TILE, oy = ty * GGS_TILE;
     const int px0 = ox + (lane & 7), py0 = oy + (lane >> 3);
-    const int L = (int)a.tile_count[(size_t)v * a.T + t];
+    const int L = overflow ? 0 : (int)a.tile_count[(size_t)v * a.T + t];
     const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
     uint32_t* ids = a.ids + base;
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
@@ -245,13 +248,13 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
 // test -> blend.  Two consecutive splats are therefore tested together (independent chains, both records read up
 // front) and blended one after the other; the arithmetic per pixel is the same as in render_fwd_body.
 __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
-    if (a.header->overflow) return;
+    const bool overflow = a.header->overflow != 0;      // see render_fwd_body: overflowed forward = all tiles empty
     const uint32_t item = a.order[blockIdx.x >> 2];
     const int q0 = (int)(blockIdx.x & 3);
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
     const int tx = t % a.gx, ty = t / a.gx;
     const int px = tx * GGS_TILE + (lane & 7) + (q0 & 1) * 8, py = ty * GGS_TILE + (lane >> 3) + (q0 >> 1) * 8;
-    const int L = (int)a.tile_count[(size_t)v * a.T + t];
+    const int L = overflow ? 0 : (int)a.tile_count[(size_t)v * a.T + t];
     const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
     uint32_t* ids = a.ids + base;
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);

@@ -27,6 +27,7 @@ def fwd_bwd_views(inputs: Dict[str, torch.Tensor], cams: Dict[str, torch.Tensor]
     grads: Optional[Dict[str, torch.Tensor]] = None
     n_total = 0
     images: List[torch.Tensor] = []
+    m2d: List[torch.Tensor] = []          # dL/dmeans2D is per view: one [V_chunk,P,3] block per launch set
     for v0 in range(0, V, chunk):
         v1 = min(V, v0 + chunk)
         color, radii, depth, alpha, st = R.forward_views(
@@ -39,14 +40,17 @@ def fwd_bwd_views(inputs: Dict[str, torch.Tensor], cams: Dict[str, torch.Tensor]
         if grads is None:
             grads = R.backward_views(st, dL, want_means2D=want_means2D)
         else:
-            if want_means2D:
-                grads.pop("means2D", None)
+            grads.pop("means2D", None)
             R.backward_views(st, dL, want_means2D=want_means2D, out=grads, accumulate=True)
+        if want_means2D:
+            m2d.append(grads["means2D"])
         if keep_images:
             images.append(color)
         del st
     grads = grads or {}
     grads["num_rendered"] = n_total
+    if want_means2D and m2d:
+        grads["means2D"] = m2d[0] if len(m2d) == 1 else torch.cat(m2d)       # [V,P,3], every view of every chunk
     if keep_images:
         grads["images"] = torch.cat(images)
     return grads

@@ -14,12 +14,14 @@ HIP kernel (ggs_mesh_bind_forward / _backward in libggsplat.so) produces xyz, sc
 rotation together, and its backward scatters straight into mesh.v.grad.  The result is cached
 per update_face_coor() call, so the three getters cost nothing extra.
 
-Disk IO (OBJ / PLY / binding.pkl), densify / prune and LBS are out of scope (SURVEY.md section 8f);
-the model is built from tensors (``from_tensors``).
+Persistence: save_ply / load_ply in the reference's PLY layout incl. binding.pkl, OBJ mesh IO
+(ggsplat.mesh_io).  Densify / prune and LBS are out of scope; the model is built from tensors (``from_tensors``) or
+from a stage-2 directory (load_mesh + load_ply).
 """
 from __future__ import annotations
 
 import ctypes as C
+import os
 from types import SimpleNamespace
 
 import torch
@@ -135,13 +137,26 @@ class MeshGaussianModel:
         (scene/mesh_gaussian_model.py:90-95 recomputes the face frames here)."""
         self._bound = None
 
+    def _bind_key(self, final: bool):
+        """What a cached binding is valid for.  The reference recomputes get_xyz / get_scaling / get_rotation from the
+        current parameters on every call (scene/mesh_gaussian_model.py:105-128), so the cache must never outlive them:
+        the key holds the identity AND the autograd version counter of every input (bumped by optimizer.step(), copy_,
+        reset_opacity, load_ply ...) and the grad mode -- a binding first evaluated under torch.no_grad() carries no
+        graph and must not be handed to a later render() that needs gradients."""
+        local = self.local_xyz if final else self._xyz
+        ins = (self.mesh.v, local, self._scaling, self._rotation, self.gs_bc, self.mesh.f, self.binding)
+        return (final, torch.is_grad_enabled()) + tuple((id(t), t._version) if t is not None else None for t in ins)
+
     def _bind(self, final: bool = False):
-        key = "final" if final else "base"
+        key = self._bind_key(final)
         if self._bound is None or self._bound[0] != key:
             local = self.local_xyz if final else self._xyz
             self._bound = (key, mesh_bind(self.mesh.v, self.mesh.f, self.binding, local, self._scaling,
                                           self._rotation, self.gs_bc))
         return self._bound[1]
+
+    def _bound_final(self) -> bool:
+        return self._bound is not None and self._bound[0][0] and self.local_xyz is not None
 
     @property
     def get_xyz(self):
@@ -153,11 +168,11 @@ class MeshGaussianModel:
 
     @property
     def get_scaling(self):
-        return self._bind(final=self._bound is not None and self._bound[0] == "final")[1]
+        return self._bind(final=self._bound_final())[1]
 
     @property
     def get_rotation(self):
-        return self._bind(final=self._bound is not None and self._bound[0] == "final")[2]
+        return self._bind(final=self._bound_final())[2]
 
     @property
     def get_opacity(self):
@@ -200,6 +215,15 @@ class MeshGaussianModel:
     @property
     def face_orien_quat(self):
         return self._face_probe()[2]
+
+    @property
+    def face_orien_mat(self):
+        """[F,3,3], columns (a0, a1 = face normal, a2) -- scene/mesh_gaussian_model.py:90-95 publishes the matrix of
+        utils/graphics_utils.py:118-137; here it is rebuilt from the kernel's unit quaternion (w,x,y,z)."""
+        r, x, y, z = self.face_orien_quat.unbind(-1)
+        return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
+                            2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
+                            2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).view(-1, 3, 3)
 
     # ---- optimisation (scene/mesh_gaussian_model.py:350-379) ----------------------------------
     def training_setup(self, training_args, is_ff: bool):
@@ -287,20 +311,68 @@ class MeshGaussianModel:
                             return_first_hit)
 
     # ---- persistence / initialisation ---------------------------------------
-    def save_ply(self, path: str):
-        """Local (mesh-frame) parameters in the reference's PLY layout (local_point_cloud.ply of
-        scene/mesh_gaussian_model.py:251-283; property order of scene/gaussian_model.py:179-209)."""
+    def find_valid_gaussians(self):
+        """scene/mesh_gaussian_model.py:284-289: Gaussians bound to a face listed in `mesh.valid_faces` (all when the
+        list is missing / empty) -- as an index tensor instead of the reference's Python list."""
+        valid = getattr(self.mesh, "valid_faces", None)
+        if valid is None or len(valid) == 0:
+            return torch.arange(self.binding.shape[0], device=self.binding.device)
+        vf = torch.as_tensor(list(valid) if not torch.is_tensor(valid) else valid, device=self.binding.device).long()
+        return torch.nonzero(torch.isin(self.binding, vf)).reshape(-1)
+
+    def save_ply(self, path: str, save_local: bool = False):
+        """scene/mesh_gaussian_model.py:251-283.  save_local=True: mesh-frame parameters (`local_point_cloud.ply`) and
+        `binding.pkl` beside it; else the world-frame values the getters produce, scaling stored as its log
+        (`point_cloud.ply`).  Property order of scene/gaussian_model.py:179-209; only the valid Gaussians are written."""
+        from .mesh_io import save_binding
         from .ply_io import save_gaussians
-        save_gaussians(path, self._xyz, self._features_dc, self._features_rest, self._opacity, self._scaling,
-                       self._rotation)
+        m = self.find_valid_gaussians()
+        with torch.no_grad():
+            if save_local:
+                xyz, scale, rot = self._xyz[m], self._scaling[m], self._rotation[m]
+            else:
+                xyz, scale, rot = self.get_xyz[m], torch.log(self.get_scaling)[m], self.get_rotation[m]
+            save_gaussians(path, xyz, self._features_dc[m], self._features_rest[m], self._opacity[m], scale, rot)
+        if save_local:
+            save_binding(os.path.join(os.path.dirname(path), "binding.pkl"), self.binding[m])
 
     def load_ply(self, path: str):
-        """scene/gaussian_model.py:216-259: parameters become plain tensors (fixed while the mesh is optimised)."""
+        """scene/mesh_gaussian_model.py:290-342: parameters become plain tensors (fixed while the mesh is optimised),
+        the binding comes from `binding.pkl` beside the PLY, and mesh.v becomes the trainable leaf."""
+        from .mesh_io import load_binding
         from .ply_io import load_gaussians
         dev = self.mesh.v.device if self.mesh is not None else "cuda"
         for k, v in load_gaussians(path, self.max_sh_degree, device=dev).items():
             setattr(self, k, v)
         self.active_sh_degree = self.max_sh_degree
+        bpath = os.path.join(os.path.dirname(path), "binding.pkl")
+        if os.path.exists(bpath):
+            self.binding = load_binding(bpath, device=dev)
+        elif self.binding is None or self.binding.shape[0] != self._xyz.shape[0]:
+            raise FileNotFoundError(f"{bpath}: a mesh-bound point cloud needs its binding.pkl")
+        self.max_radii2D = torch.zeros(self._xyz.shape[0], device=dev)
+        if self.mesh is not None:
+            self.mesh.v = nn.Parameter(self.mesh.v.detach().clone().requires_grad_(True))
+        self._bound = None
+
+    def save_mesh(self, path: str):
+        """scene/mesh_gaussian_model.py:438-441: the template's OBJ (uvs / faces / texture faces) with the current
+        vertices."""
+        from .mesh_io import write_obj
+        out = dict(getattr(self, "template", None) or {"faces": self.mesh.f.detach().cpu().numpy()})
+        out["vertices"] = self.mesh.v.detach().cpu().numpy()
+        write_obj(out, path)
+
+    def load_mesh(self, path: str, device=None):
+        """A registered frame's mesh (scene/scene.py:155-156): vertices replace mesh.v (faces too when the model has
+        none yet); the template dictionary is kept for save_mesh."""
+        from .mesh_io import read_obj
+        d = read_obj(path)
+        dev = device or (self.mesh.v.device if self.mesh is not None else self._xyz.device if self._xyz.numel() else "cuda")
+        if self.mesh is None:
+            self.mesh = SimpleNamespace(v=None, f=torch.from_numpy(d["faces"]).long().to(dev).contiguous())
+        self.mesh.v = nn.Parameter(torch.from_numpy(d["vertices"]).to(dev).contiguous())
+        self.template = {k: v for k, v in d.items() if getattr(v, "size", 0)}
         self._bound = None
 
     def init_scaling_from_neighbours(self, points: torch.Tensor) -> torch.Tensor:

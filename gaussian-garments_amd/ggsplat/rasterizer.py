@@ -16,6 +16,7 @@ the native backward.  Call site being served: gaussian_renderer/__init__.py:54,
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -75,14 +76,19 @@ def _workspace_sizes(L, prm, cap: int) -> Tuple[int, int, int]:
     return r
 
 
-_pinned: Dict = {}
+_pinned = threading.local()
 _tanfov_cache: Dict = {}
 
 
 def _pinned_header(dev) -> torch.Tensor:
-    t = _pinned.get(dev.index)
+    """Pinned int64[2] landing buffer of the header read-back, one per (thread, device): two threads (eval workers,
+    multi-stream batching) calling forward_views concurrently must not read each other's num_rendered / overflow."""
+    d = getattr(_pinned, "buf", None)
+    if d is None:
+        d = _pinned.buf = {}
+    t = d.get(dev.index)
     if t is None:
-        t = _pinned[dev.index] = torch.empty(2, dtype=torch.int64, pin_memory=True)
+        t = d[dev.index] = torch.empty(2, dtype=torch.int64, pin_memory=True)
     return t
 
 
@@ -104,7 +110,7 @@ def _stream_ptr(dev) -> C.c_void_p:
 class ForwardState:
     """Everything the backward needs (the reference keeps the same things in ctx)."""
     __slots__ = ("prm", "bg", "means3D", "shs", "colors", "opac", "scales", "rots", "cov", "view", "proj",
-                 "campos", "tanfov", "geom", "bin", "cap", "img", "num_rendered")
+                 "campos", "tanfov", "geom", "bin", "cap", "img", "num_rendered", "header")
 
 
 def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, *, view, proj, campos,
@@ -196,6 +202,7 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
         st.prm, st.bg, st.means3D, st.shs, st.colors, st.opac = prm, bg, means3D, shs, colors_precomp, opacities
         st.scales, st.rots, st.cov, st.view, st.proj, st.campos, st.tanfov = scales, rotations, cov3D_precomp, view, proj, campos, tanfov
         st.geom, st.bin, st.cap, st.img, st.num_rendered = geom, binb, cap, img, n
+        st.header = _last_header                      # device int64[2] {num_rendered, overflow} of THIS call
     return color, radii, depth, alpha, st
 
 
@@ -272,6 +279,13 @@ class _RasterizeGaussians(torch.autograd.Function):
             scale_modifier=settings.scale_modifier, debug=settings.debug, keep_state=True)
         ctx.set_materialize_grads(False)      # unused depth / alpha outputs -> None, not zeros
         ctx.st = st
+        # The backward recomputes cov3D / SH colours from the INPUTS (they are not copied), so an in-place edit between
+        # forward and backward would silently change the gradients.  save_for_backward would also hold the outputs'
+        # graph alive for callers that mutate them; recording the version counters gives the same protection: the
+        # upstream extension raises autograd's "modified by an inplace operation" error in that situation, so do we.
+        ctx.in_versions = [(n, t, t._version) for n, t in (("means3D", means3D), ("sh", sh), ("colors_precomp", colors_precomp),
+                                                            ("opacities", opacities), ("scales", scales), ("rotations", rotations),
+                                                            ("cov3Ds_precomp", cov3Ds_precomp)) if t is not None]
         ctx.m2d_shape = means2D.shape
         # Outputs are never saved: callers mutate them in place (ssim does `img1 *= mask`,
         # utils/loss_utils.py:44-46).  For the same reason they must not be VIEWS created inside this
@@ -284,6 +298,10 @@ class _RasterizeGaussians(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_color, g_radii, g_depth, g_alpha):
         st = ctx.st
+        for name, t, ver in ctx.in_versions:
+            if t._version != ver:
+                raise RuntimeError(f"one of the variables needed for gradient computation has been modified by an inplace "
+                                   f"operation: rasterizer input `{name}` is at version {t._version}; expected version {ver}")
         H, W = st.prm.H, st.prm.W
         if g_color is None:
             g_color = torch.zeros(3, H, W, device=st.means3D.device)

@@ -558,7 +558,8 @@ void ggo_backward(const void* h, const float* bg, const float* means3D, const fl
             for (int k = 0; k < 3; ++k) {
                 float acc = 0.f;
                 for (int j = 0; j < 3; ++j) { acc += dMm[k * 3 + j] * R[j * 3 + k]; dR[j * 3 + k] = sv[k] * dMm[k * 3 + j]; }
-                osc[k] = prm->scale_modifier * acc;
+                /* upstream returns dL/d(modifier*scale) as dL/dscale (no chain-rule factor `modifier`): reproduced */
+                osc[k] = acc;
             }
             float r = qq[0], x = qq[1], y = qq[2], z = qq[3];
             float* oq = dL_drots + 4 * (size_t)i;

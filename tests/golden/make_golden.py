@@ -158,6 +158,42 @@ def schedule_golden():
     np.savez(os.path.join(OUT, "lr_schedule.npz"), **rec)
 
 
+def cov3d_golden():
+    """build_rotation / build_scaling_rotation / strip_symmetric (utils/general_utils.py:74-120) and the covariance
+    built from them exactly as scene/gaussian_model.py:27-31 does (`L = build_scaling_rotation(modifier * scaling,
+    rotation); strip_symmetric(L @ L.transpose(1, 2))`).  The three functions allocate with a hard-coded
+    device="cuda"; the module's `torch` name is swapped for a proxy whose zeros() drops that keyword, so the
+    reference's own arithmetic runs on the CPU unchanged."""
+    import types
+    for name in ("open3d", "scene", "scene.cameras"):
+        sys.modules.setdefault(name, types.ModuleType(name))
+    sys.modules["scene.cameras"].Camera = object
+    import utils.general_utils as GU
+
+    class _CpuTorch:
+        def __getattr__(self, k):
+            return getattr(torch, k)
+
+        @staticmethod
+        def zeros(*a, **kw):
+            kw.pop("device", None)
+            return torch.zeros(*a, **kw)
+    real = GU.torch
+    GU.torch = _CpuTorch()
+    try:
+        g = torch.Generator().manual_seed(7)
+        s = torch.rand(50, 3, generator=g) * 0.2 + 0.005
+        q = torch.randn(50, 4, generator=g)                       # NOT normalised: build_rotation normalises
+        rec = {"scales": s.numpy(), "rots": q.numpy(), "R": GU.build_rotation(q).numpy()}
+        for tag, mod in (("1", 1.0), ("1p3", 1.3)):
+            L = GU.build_scaling_rotation(mod * s, q)
+            rec[f"L_{tag}"] = L.numpy()
+            rec[f"cov6_{tag}"] = GU.strip_symmetric(L @ L.transpose(1, 2)).numpy()
+    finally:
+        GU.torch = real
+    np.savez(os.path.join(OUT, "cov3d.npz"), **rec)
+
+
 if __name__ == "__main__":
-    sh_golden(); camera_golden(); face_golden(); loss_golden(); stylegan_golden(); schedule_golden()
+    sh_golden(); camera_golden(); face_golden(); loss_golden(); stylegan_golden(); schedule_golden(); cov3d_golden()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))

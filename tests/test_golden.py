@@ -125,20 +125,37 @@ def test_loss_matches_reference(tag):
     assert np.allclose(x.grad.numpy(), d[f"ssim_grad_{tag}"], rtol=1e-4, atol=1e-8)
 
 
-def test_cov3d_matches_reference_python_path():
-    """scale/rotation -> cov3D as get_covariance does it (scene/gaussian_model.py:27-31,
-    utils/general_utils.py:91-120: L = R(normalised q) @ diag(s); Sigma = L L^T; strip to 6)."""
-    g = torch.Generator().manual_seed(7)
-    s = torch.rand(50, 3, generator=g) + 0.1
-    q = torch.nn.functional.normalize(torch.randn(50, 4, generator=g))
-    r, x, y, z = q.unbind(-1)
-    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y),
-                     2 * (x * y + r * z), 1 - 2 * (x * x + z * z), 2 * (y * z - r * x),
-                     2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], -1).view(-1, 3, 3)
-    Lm = R @ torch.diag_embed(1.3 * s)
-    S = Lm @ Lm.transpose(1, 2)
-    ref = torch.stack([S[:, 0, 0], S[:, 0, 1], S[:, 0, 2], S[:, 1, 1], S[:, 1, 2], S[:, 2, 2]], -1)
-    assert np.allclose(TO.cov3d_from_scale_rot(s, 1.3, q).numpy(), ref.numpy(), rtol=1e-5, atol=1e-7)
+def _cov3d_case(tag):
+    d = _load("cov3d.npz")
+    s, q = torch.tensor(d["scales"]), torch.tensor(d["rots"])
+    return d, s, torch.nn.functional.normalize(q), {"1": 1.0, "1p3": 1.3}[tag]
+
+
+@pytest.mark.parametrize("tag", ["1", "1p3"])
+def test_cov3d_matches_reference_python_path(tag):
+    """scale/rotation -> cov3D pinned to the fixture generated from the reference's own build_rotation /
+    build_scaling_rotation / strip_symmetric (utils/general_utils.py:74-120) composed as get_covariance composes them
+    (scene/gaussian_model.py:27-31).  Both restatements are checked: the torch oracle and the C oracle's stage
+    (internals()['cov3d']).  The reference normalises the quaternion inside build_rotation; the rasterizer's stage
+    takes unit quaternions, so they are normalised here."""
+    d, s, qn, mod = _cov3d_case(tag)
+    ref = d[f"cov6_{tag}"]
+    assert np.allclose(TO.quat_to_rotmat(qn).numpy(), d["R"], atol=1e-6)
+    assert np.allclose(TO.cov3d_from_scale_rot(s, mod, qn).numpy(), ref, rtol=2e-5, atol=1e-9)
+    from oracle.c_oracle import COracle
+    from ggsplat import synthetic as S
+    from helpers import cam_kwargs
+    cam = S.orbit_cameras(4, width=64, img_height=48, fx=70.0, fy=70.0, cx=31.0, cy=25.0)[0]
+    P = s.shape[0]
+    g = torch.Generator().manual_seed(1)
+    means = torch.randn(P, 3, generator=g) * 0.3
+    co = COracle(means3D=means, opacities=torch.full((P, 1), 0.5), colors_precomp=torch.rand(P, 3, generator=g),
+                 scales=s, rotations=qn, scale_modifier=mod, **cam_kwargs(cam, [0, 0, 0]))
+    assert np.allclose(co.internals()["cov3d"], ref, rtol=2e-5, atol=1e-9)
+    # ... and the API identity the reference guarantees: render(scales, rots) == render(cov3D_precomp = that Sigma)
+    co2 = COracle(means3D=means, opacities=torch.full((P, 1), 0.5), colors_precomp=torch.rand(P, 3, generator=torch.Generator().manual_seed(1)),
+                  cov3D_precomp=torch.tensor(ref), **cam_kwargs(cam, [0, 0, 0]))
+    assert np.array_equal(co.radii, co2.radii)
 
 
 @pytest.mark.parametrize("name", ["s2_xyz", "delayed", "off"])

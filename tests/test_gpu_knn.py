@@ -41,10 +41,30 @@ def test_ply_round_trip_through_model(tmp_path):
     p = S.skirt_gaussian_params(f.shape[0], sh_degree=2)
     m = MeshGaussianModel.from_tensors(v, f, p, sh_degree=2, device="cuda")
     path = str(tmp_path / "point_cloud" / "frame_00000" / "local_point_cloud.ply")
-    m.save_ply(path)
+    m.save_ply(path, save_local=True)
     m2 = MeshGaussianModel.from_tensors(v, f, S.skirt_gaussian_params(f.shape[0], sh_degree=2, seed=9), sh_degree=2, device="cuda")
     m2.load_ply(path)
     for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"):
         assert torch.equal(getattr(m2, k).cpu(), getattr(m, k).detach().cpu()), k
     m.update_face_coor(); m2.update_face_coor()
     assert torch.equal(m.get_xyz, m2.get_xyz) and torch.equal(m.get_rotation, m2.get_rotation)
+
+
+def test_world_frame_ply_holds_the_getters(tmp_path):
+    """save_ply(save_local=False) (scene/mesh_gaussian_model.py:261-264): world positions, log of the world scaling,
+    world rotation -- i.e. what the fused mesh-binding kernel produces."""
+    from ggsplat import ply_io, synthetic as S
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    v, f = S.skirt_mesh(12, 6)
+    p = S.skirt_gaussian_params(f.shape[0], sh_degree=1)
+    m = MeshGaussianModel.from_tensors(v, f, p, sh_degree=1, device="cuda")
+    m.mesh.valid_faces = list(range(0, f.shape[0], 2))            # only Gaussians on the valid faces are written
+    path = str(tmp_path / "point_cloud" / "frame_00003" / "point_cloud.ply")
+    m.save_ply(path)
+    d = ply_io.load_gaussians(path, 1, device="cpu")
+    keep = torch.arange(0, f.shape[0], 2)
+    m.update_face_coor()
+    assert torch.equal(d["_xyz"], m.get_xyz.detach().cpu()[keep])
+    assert torch.equal(d["_scaling"], torch.log(m.get_scaling).detach().cpu()[keep])
+    assert torch.equal(d["_rotation"], m.get_rotation.detach().cpu()[keep])
+    assert not (tmp_path / "point_cloud" / "frame_00003" / "binding.pkl").exists()

@@ -1,8 +1,9 @@
 """GPU parity: HIP path (through the C ABI, via the drop-in module) vs the C oracle.
 
-Bars (north_star): bit-exact for integer / index outputs (radii, num_rendered, per-pixel
-contributor counts, per-tile sorted id lists); <= 1e-4 relative L1 for fp32 images and
-gradients (tolerance REL_L1_TOL in helpers.py).
+Bars (north_star): bit-exact for integer / index outputs -- radii; the per-tile sorted id lists (exact subsequences of
+the oracle's lists, every dropped pair proven unblendable); the Gaussian id of every pixel's last contributor (the
+per-pixel counts themselves are positions in differently culled lists and are compared through that id) -- and
+<= 1e-4 relative L1 for fp32 images and gradients (tolerance REL_L1_TOL in helpers.py).
 """
 import math
 
@@ -164,6 +165,19 @@ def test_internals_bit_exact():
                 power = -0.5 * (con[g, 0] * dx * dx + con[g, 2] * dy * dy) - con[g, 1] * dx * dy
                 a_ = np.where(power > 0, 0.0, np.minimum(0.99, con[g, 3] * np.exp(np.minimum(power, 0))))
                 assert a_.max() < 1.0 / 255.0, f"tile {t}: dropped splat {g} would have been blended"
+    # Index output of the compositing: the LAST CONTRIBUTOR of every pixel.  n_contrib is a 1-based position in the
+    # tile's list -- the culled list here, the full list in the oracle -- so the comparable quantity is the Gaussian id
+    # found at that position: it must be the same Gaussian, pixel for pixel (and 0 contributors in the same pixels).
+    n_hip = img[st.img.numel() // 2:][:HW * 4].view(torch.int32).reshape(120, 160).numpy().astype(np.int64)
+    n_ref = it["n_contrib"].astype(np.int64)
+    ty, tx = np.meshgrid(np.arange(120) // 16, np.arange(160) // 16, indexing="ij")
+    tile = ty * gx + tx
+    assert np.array_equal(n_hip > 0, n_ref > 0)
+    has = n_ref > 0
+    last_hip = ids[(offs[tile] + n_hip - 1)[has]].astype(np.int64)
+    last_ref = it["list"][(it["tile_start"][tile] + n_ref - 1)[has]].astype(np.int64)
+    assert np.array_equal(last_hip, last_ref), f"{int((last_hip != last_ref).sum())} of {int(has.sum())} pixels end on another Gaussian"
+    assert has.sum() > 0.3 * HW
     # per-Gaussian records: bit-exact geometry (floats 0..9 of the 48-byte record)
     rec = st.geom.cpu()[:3000 * 48].view(torch.float32).reshape(3000, 12).numpy()
     vis = co.radii > 0
@@ -276,3 +290,34 @@ def S_random(P):
 def S_orbit():
     from ggsplat import synthetic as S
     return S.orbit_cameras(4)
+
+
+@pytest.mark.parametrize("tag,mod", [("1", 1.0), ("1p3", 1.3)])
+def test_cov3d_stage_against_the_reference_fixture(tag, mod):
+    """The scale/rotation -> cov3D stage of the HIP preprocess, pinned to tests/golden/cov3d.npz (generated from the
+    reference's build_scaling_rotation / strip_symmetric, utils/general_utils.py:91-120): rendering from (scales,
+    rotations, scale_modifier) must equal rendering from cov3D_precomp = the reference's own Sigma -- same radii, same
+    image, same depth / alpha."""
+    import os
+    from ggsplat import rasterizer as R
+    from ggsplat import synthetic as S
+    from ggsplat.synthetic import stack_cameras
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "cov3d.npz"))
+    dev = "cuda"
+    s = torch.tensor(d["scales"]).to(dev)
+    qn = torch.nn.functional.normalize(torch.tensor(d["rots"])).to(dev)
+    cov = torch.tensor(d[f"cov6_{tag}"]).to(dev)
+    P = s.shape[0]
+    g = torch.Generator().manual_seed(1)
+    means = (torch.randn(P, 3, generator=g) * 0.3).to(dev)
+    cols = torch.rand(P, 3, generator=g).to(dev)
+    op = torch.full((P, 1), 0.6, device=dev)
+    cam = S.orbit_cameras(4, width=96, img_height=64, fx=110.0, fy=110.0, cx=47.0, cy=33.0)[0]
+    ck = stack_cameras([cam], device=dev)
+    kw = dict(view=ck["view"], proj=ck["proj"], campos=ck["campos"], tanfov=ck["tanfov"], bg=torch.zeros(3, device=dev),
+              W=96, H=64, sh_degree=0, keep_state=False)
+    a = R.forward_views(means, op, None, cols, s, qn, None, scale_modifier=mod, **kw)
+    b = R.forward_views(means, op, None, cols, None, None, cov, **kw)
+    assert int((a[1] > 0).sum()) > P // 2 and torch.equal(a[1], b[1])
+    for x, y in zip((a[0], a[2], a[3]), (b[0], b[2], b[3])):
+        assert rel_l1(x, y) <= 1e-5

@@ -176,3 +176,26 @@ def test_ragged_image_sizes():
     """W, H not multiples of 16: partial tiles on the right / bottom edges."""
     sc, cam = small_scene(P=300, W=37, H=21, sh_degree=0, seed=4, scale_mul=8.0)
     _both(sc, cam, (0.3, 0.3, 0.3), da=False)
+
+
+def test_scale_modifier_gradient_follows_upstream():
+    """scale_modifier != 1: every gradient equals autograd's EXCEPT dL/dscales, which upstream's computeCov3D backward
+    returns without the chain-rule factor `modifier` (it differentiates w.r.t. S = modifier * scale).  The oracle and
+    the HIP kernel reproduce upstream: oracle dL/dscales * modifier == autograd dL/dscales."""
+    mod = 0.7
+    sc, cam = small_scene(P=300, W=64, H=48, sh_degree=0, seed=23, scale_mul=5.0)
+    kw = cam_kwargs(cam, (1.0, 1.0, 1.0))
+    leaf = {k: sc[k].clone().requires_grad_(True) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    col, radii, dep, alp = TO.rasterize(leaf["means3D"], torch.zeros(300, 3), leaf["opacities"], shs=leaf["shs"],
+                                        scales=leaf["scales"], rotations=leaf["rotations"], sh_degree=0,
+                                        scale_modifier=mod, **kw)
+    wc, _, _ = seeded_image_weights(cam.image_width, cam.image_height)
+    (col * wc).sum().backward()
+    co = COracle(means3D=sc["means3D"], opacities=sc["opacities"], shs=sc["shs"], scales=sc["scales"],
+                 rotations=sc["rotations"], sh_degree=0, scale_modifier=mod, **kw)
+    g = co.backward(wc)
+    assert np.array_equal(co.radii, radii.numpy())
+    for k in ("means3D", "opacities", "shs", "rotations"):
+        assert rel_l1(g[k].reshape(leaf[k].shape), leaf[k].grad) < TOL, k
+    assert rel_l1(g["scales"] * mod, leaf["scales"].grad) < TOL
+    assert rel_l1(g["scales"], leaf["scales"].grad) > 0.1          # i.e. NOT the exact derivative
