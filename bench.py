@@ -264,17 +264,26 @@ def main():
         dom_bytes = B[dom] * chunk
         achieved = dom_bytes / (group_ms[dom] * 1e-3) / 1e9
         B_view = sum(B.values())
-        # HBM bytes per launch from the PMC counters (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes,
-        # tools/hbm_traffic.sh; committed under profiles/ because bench.py cannot run a profiler on itself)
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")))
-            if args.sh_degree == 0 and (W, H, Fn) == (1920, 1080, 100000):
-                traffic = int(tj["kernels"]["ggs_k_" + dom]["traffic_per_view"] * chunk)
-        except Exception:
-            traffic = None
+        # HBM bytes per launch from the PMC counters (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE in separate passes,
+        # tools/hbm_traffic.sh -> profiles/rNN_hbm_traffic.json; bench.py cannot run a profiler on itself).  A collection
+        # is only used when it was taken from THIS build (same ggs_build_id) and this workload; otherwise null.
+        traffic, traffic_src = None, None
+        bid = _lib.build_id()
+        for fn in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.json")), reverse=True):
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                wl = tj.get("workload", {})
+                if tj.get("build_id") == bid and wl == {"P": Fn, "W": W, "H": H, "sh_degree": args.sh_degree}:
+                    traffic = int(tj["kernels"]["ggs_k_" + dom + ("_sh%d" % args.sh_degree if dom == "preprocess_bwd" else "")]
+                                  ["traffic"] / tj["views_per_launch"] * chunk)
+                    traffic_src = "profiles/" + fn
+                    break
+            except Exception:
+                continue
         roofline = {"bound": "hbm", "kernel": "ggs_k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    "traffic_source": traffic_src if traffic is not None else
+                    f"none: no profiles/*_hbm_traffic.json was collected from build {bid} on this workload",
                     "launch_views": chunk, "launch_ms": round(group_ms[dom], 4),
                     "alg_bytes_per_launch": int(dom_bytes),
                     "kernel_ms_per_launch": {k: round(v, 4) for k, v in kern_ms.items()},
@@ -368,6 +377,25 @@ def main():
             cpu = {"value": round(n_cpu / cpu_dt, 4), "unit": "views/s", "cores": os.cpu_count(), "kind": "port",
                    "sample": f"{n_cpu} of the {len(all_cams)} views of the same workload, fwd+bwd, "
                              f"oracle/splat_oracle.c with OpenMP on {os.cpu_count()} threads"}
+            # BASELINE.json configs[0] (the reference's own CPU-runnable case) in full: 10k free Gaussians, SH degree 3,
+            # 4 cameras 512x512, fwd+bwd, median of 3 passes after one warm-up pass
+            sc1 = S.random_gaussians(10_000, sh_degree=3, seed=0)
+            cams1 = S.orbit_cameras(4)
+            w1 = torch.randn(3, 512, 512, generator=torch.Generator().manual_seed(5))
+            times = []
+            for rep in range(4):
+                t1 = time.perf_counter()
+                for c in cams1:
+                    co = COracle(means3D=sc1["means3D"], opacities=sc1["opacities"], shs=sc1["shs"], scales=sc1["scales"],
+                                 rotations=sc1["rotations"], viewmatrix=c.world_view_transform,
+                                 projmatrix=c.full_proj_transform, campos=c.camera_center, bg=torch.zeros(3), W=512, H=512,
+                                 tanfovx=math.tan(c.FoVx * 0.5), tanfovy=math.tan(c.FoVy * 0.5), sh_degree=3)
+                    co.backward(w1)
+                    co.close()
+                times.append(time.perf_counter() - t1)
+            cpu["config1"] = {"value": round(4 / sorted(times[1:])[1], 3), "unit": "views/s",
+                              "sample": "BASELINE configs[0] in full: 10k Gaussians, SH degree 3, 4 cameras 512x512, fwd+bwd, "
+                                        "median of 3 passes"}
 
         out = {
             "metric": "fwd+bwd views/sec @1080p, 100k mesh-Gaussians",
@@ -383,6 +411,7 @@ def main():
                        "mean_list_length_per_pixel": round(N_view / T, 2),
                        "mean_last_contributor_per_pixel": round(mean_contrib, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
+            "build_id": bid, "library_matches_sources": bid == _lib.source_hash(),
             "per_view_loop_views_per_sec": None if loop_vps is None else round(loop_vps, 2),
             "s2_inner_step_iters_per_sec": None if step_vps is None else round(step_vps, 2),
             "s2_graph_step_iters_per_sec": None if graph_vps is None else round(graph_vps, 2),

@@ -138,7 +138,11 @@ Dims dims(const GgsParams* p) {
 extern "C" {
 
 const char* ggs_last_error(void) { return g_err; }
-const char* ggs_version(void) { return "ggsplat 0.1 gfx950"; }
+const char* ggs_version(void) { return "ggsplat 0.2 gfx950"; }
+#ifndef GGS_SRC_HASH
+#define GGS_SRC_HASH "unknown"
+#endif
+const char* ggs_build_id(void) { return GGS_SRC_HASH; }
 
 int ggs_profile_enable(int on) { g_prof.on = on != 0; return GGS_OK; }
 

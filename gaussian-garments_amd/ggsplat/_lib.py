@@ -58,6 +58,7 @@ _SIGS = {
     "ggs_profile_read": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
     "ggs_last_error": (C.c_char_p, []),
     "ggs_version": (C.c_char_p, []),
+    "ggs_build_id": (C.c_char_p, []),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -92,3 +93,23 @@ def ptr(t):
         return None
     assert t.is_contiguous(), "ggsplat: tensor must be contiguous"
     return t.data_ptr()             # ctypes converts the int for the void* parameters (no c_void_p object per argument)
+
+
+_SRC_ORDER = ("ggs_pergauss.hip", "ggs_binning.hip", "ggs_render.hip", "ggs_mesh.hip", "ggs_loss.hip", "ggs_knn.hip",
+              "ggs_stylegan.hip", "ggs_visibility.hip", "ggs_adam.hip", "ggs_regaux.hip", "ggs_api.hip", "ggs_common.h",
+              "ggs_kernels.h", os.path.join("..", "..", "include", "ggsplat.h"))
+
+
+def source_hash() -> str:
+    """The id `make` would bake into a library built from the sources on disk now (csrc/Makefile SRC_HASH)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.dirname(LIB_PATH)
+    for name in _SRC_ORDER:
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_id() -> str:
+    return lib().ggs_build_id().decode()

@@ -65,7 +65,10 @@ typedef struct GgsParams {
 /* Layout of the first 16 bytes of the binning buffer: read it back (async copy)
  * to learn num_rendered and whether `bin_capacity` was too small. */
 typedef struct GgsBinHeader {
-    unsigned long long num_rendered; /* sum over views of tiles touched (N)                   */
+    unsigned long long num_rendered; /* sum over views of the (splat, tile) list entries the library KEEPS: the
+                                      * reference's 3-sigma-square rule minus the pairs whose alpha can never reach
+                                      * 1/255 inside the tile (output-invariant culling; e.g. 337k vs 462k per view
+                                      * at config 2).  It sizes `bin_capacity`; it is NOT the upstream num_rendered. */
     unsigned long long overflow;     /* != 0: N > bin_capacity, outputs are invalid; retry     */
 } GgsBinHeader;
 
@@ -271,6 +274,9 @@ const char* ggs_last_error(void);
 
 /* Library version / build target string, e.g. "ggsplat 0.1 gfx950". */
 const char* ggs_version(void);
+/* First 16 hex digits of the sha256 over the library's sources (csrc Makefile order): identifies the build a profile or a
+ * counter collection belongs to.  No reference counterpart (the upstream extension carries no build id). */
+const char* ggs_build_id(void);
 
 #ifdef __cplusplus
 }

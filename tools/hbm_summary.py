@@ -22,7 +22,7 @@ def per_kernel(path, counter):
     return out
 
 
-def main(fetch_db, write_db, out_prefix, views=32):
+def main(fetch_db, write_db, out_prefix, views=32, build_id="", workload=None):
     f, w = per_kernel(fetch_db, "FETCH_SIZE"), per_kernel(write_db, "WRITE_SIZE")
     src = ("rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) --kernel-trace -- python bench.py "
            f"--steps 1 --warmup 0 --cpu-views 0 --loop-views 0 --views {views}")
@@ -34,10 +34,11 @@ def main(fetch_db, write_db, out_prefix, views=32):
         fr, wr = f.get(k, (0, 0.0))[1], w.get(k, (0, 0.0))[1]
         kern[k] = {"fetch_raw": fr, "fetch_x2": 2 * fr, "write": wr, "traffic": 2 * fr + wr,
                    "traffic_per_view": (2 * fr + wr) / views, "dispatches": f.get(k, w.get(k))[0]}
-    json.dump({"source": src, "views_per_launch": views, "note": note, "kernels": kern},
+    json.dump({"source": src, "views_per_launch": views, "build_id": build_id,
+               "workload": workload or {"P": 100000, "W": 1920, "H": 1080, "sh_degree": 0}, "note": note, "kernels": kern},
               open(out_prefix + ".json", "w"), indent=1)
     with open(out_prefix + ".md", "w") as md:
-        md.write(f"# HBM traffic per kernel (rocprofv3 PMC)\n\n{src}\n\n{note}\n\n")
+        md.write(f"# HBM traffic per kernel (rocprofv3 PMC), build {build_id}\n\n{src}\n\n{note}\n\n")
         md.write("| kernel | FETCH_SIZE raw MB | x2 MB | WRITE_SIZE MB | traffic MB / launch | MB / view |\n|---|---|---|---|---|---|\n")
         for k, v in kern.items():
             md.write(f"| {k} | {v['fetch_raw']/1e6:.1f} | {v['fetch_x2']/1e6:.1f} | {v['write']/1e6:.1f} | "
@@ -45,4 +46,9 @@ def main(fetch_db, write_db, out_prefix, views=32):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 32)
+    # argv: fetch.db write.db out_prefix [views] [build_id] [P W H sh_degree]
+    wl = None
+    if len(sys.argv) > 9:
+        wl = dict(zip(("P", "W", "H", "sh_degree"), map(int, sys.argv[6:10])))
+    main(sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 32,
+         sys.argv[5] if len(sys.argv) > 5 else "", wl)

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One GPU-box call -> everything profiles/ needs for ONE workload of bench.py, all from the same build:
+#   tools/profile_all.sh TAG [bench.py workload flags, e.g. --sh-degree 3]
+#   1. kernel trace (rocprofv3 --kernel-trace --stats) of `bench.py --steps 3 --warmup 1`   -> gpurun_out/TAG_trace
+#   2. SQ instruction / wave-cycle counters (one --pmc pass, kernel-trace only)              -> gpurun_out/TAG_sq
+#   3. FETCH_SIZE and 4. WRITE_SIZE in SEPARATE --pmc passes (TCC slots; MI355X_MICROARCH.md, HBM section)
+# No other tracing domain is ever combined with --pmc.  The build id of the library is recorded beside the results;
+# tools/profile_summary.py turns the .db files into the tables under profiles/.
+set -e
+TAG=$1; shift
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/$TAG
+mkdir -p $R/gpurun_out
+BENCH="python $R/bench.py --cpu-views 0 --loop-views 0 $*"
+python -c "import sys; sys.path.insert(0, '$R/gaussian-garments_amd'); from ggsplat import _lib; print(_lib.build_id())" > ${OUT}_build_id.txt
+echo "$*" > ${OUT}_args.txt
+timeout 600 rocprofv3 --kernel-trace --stats -d ${OUT}_trace -o t -- $BENCH --steps 3 --warmup 1 > ${OUT}_trace.log 2>&1 || echo "trace pass failed" >> ${OUT}_trace.log
+PMC="$BENCH --steps 1 --warmup 0 --views 32"
+timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d ${OUT}_sq -o s -- $PMC > ${OUT}_sq.log 2>&1 || echo "sq pass failed" >> ${OUT}_sq.log
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d ${OUT}_fetch -o f -- $PMC > ${OUT}_fetch.log 2>&1 || echo "fetch pass failed" >> ${OUT}_fetch.log
+timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d ${OUT}_write -o w -- $PMC > ${OUT}_write.log 2>&1 || echo "write pass failed" >> ${OUT}_write.log
+# keep only the databases (the merge back is capped at 64 MiB)
+find ${OUT}_trace ${OUT}_sq ${OUT}_fetch ${OUT}_write -type f ! -name '*.db' -delete 2>/dev/null || true
+grep -h '^{' ${OUT}_trace.log | tail -1 > ${OUT}_bench.json || true
+ls -la ${OUT}_* | head -20
