@@ -1,0 +1,318 @@
+"""The two inner steps at BASELINE size (100 000 mesh-bound Gaussians, 1920x1080) against the oracle PIPELINE, and
+their hipGraph-replayed forms against the eager steps (configs[2] / configs[3] of BASELINE.json).
+
+Oracle pipeline = the same step assembled on the host from the checkers only:
+    host_oracle.mesh_bind (autograd)  ->  C oracle forward  ->  host_oracle L1 / SSIM (autograd, gives dL/dimage)
+    ->  C oracle backward  ->  autograd back through mesh binding, activations, the net's offsets and the hinge terms.
+It follows s2_registration.py:238-327 and s3_appearance.py:107-149 + gaussian_renderer/__init__.py:56,87,92-100 (the
+`pc.shs` / `get_final_xyz` selection and the boolean gather of the visible Gaussians).
+
+  * s3 form (config 4): texel-bound Gaussians (barycentric origins), SH degree 3 (K = 16), `vis_mask` ~ 50 % true,
+    `local_xyz = _xyz + net offset`, `shs = features + net offset`, five-term loss: loss terms, image, radii, EVERY
+    gradient (Gaussian parameters, mesh.v, the net's two offset tensors).
+  * s2 form (config 2): K = 1, hinge terms over the visible Gaussians, densification statistics.
+  * GraphedRegistrationStep (lean) and GraphedAppearanceStep at the same size: loss terms and the post-Adam parameters
+    against the eager step with torch.optim.Adam.
+"""
+import math
+from types import SimpleNamespace
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import REL_L1_TOL, rel_l1
+from ggsplat import synthetic as S
+from oracle import host_oracle as HO
+from oracle.c_oracle import COracle
+
+pytestmark = pytest.mark.gpu
+W, H = 1920, 1080
+NAMES = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+
+
+def _cam_to(cam, dev):
+    for n in ("world_view_transform", "full_proj_transform", "camera_center"):
+        setattr(cam, n, getattr(cam, n).to(dev))
+    return cam
+
+
+def _images(seed):
+    g = torch.Generator().manual_seed(seed)
+    gt = torch.rand(3, H // 8, W // 8, generator=g)
+    gt = F.interpolate(gt[None], size=(H, W), mode="bilinear", align_corners=False)[0].contiguous()   # smooth "photo"
+    mask = (F.interpolate(torch.rand(1, 1, H // 16, W // 16, generator=g), size=(H, W), mode="nearest")[0] > 0.15).float()
+    return gt, mask
+
+
+def _same_inputs(model, host, vis_mask=None, final=False, shs=None):
+    """The rasterizer inputs of the GPU step (the fused mesh-binding kernel's outputs, sigmoid, cat), checked against
+    the host oracle's and then handed to the C oracle AS THEY ARE: the rasterizer stage is compared on bit-identical
+    inputs.  (One-ulp differences between the two binding implementations move pixel means by ~1e-4 px; under a smooth
+    loss gradient the position gradients are sums that cancel to ~1 % of their terms, and that perturbation alone shows
+    up as ~1e-4 relative L1 in them -- measured, tools/dbg/s2_step_grad.py.)"""
+    with torch.no_grad():
+        gpu = [model.get_final_xyz if final else model.get_xyz, model.get_scaling, model.get_rotation, model.get_opacity,
+               model.get_features if shs is None else shs]
+        gpu = [t.detach().cpu() if vis_mask is None else t.detach().cpu()[vis_mask] for t in gpu]
+    for a, b in zip(gpu, host):
+        assert rel_l1(a, b) <= 1e-6
+    return gpu
+
+
+def _c_render(cam, xyz, scaling, rot, opacity, shs, sh_degree, bg):
+    """C oracle forward; returns (oracle handle, image leaf [3,H,W])."""
+    co = COracle(means3D=xyz.detach(), opacities=opacity.detach(), shs=shs.detach(), scales=scaling.detach(),
+                 rotations=rot.detach(), viewmatrix=cam.world_view_transform.cpu(), projmatrix=cam.full_proj_transform.cpu(),
+                 campos=cam.camera_center.cpu(), bg=bg.cpu(), W=W, H=H, tanfovx=math.tan(cam.FoVx * 0.5),
+                 tanfovy=math.tan(cam.FoVy * 0.5), sh_degree=sh_degree)
+    return co, torch.from_numpy(co.color.copy()).requires_grad_(True)
+
+
+def _gpu_loss_grad(pkg, gt, mask, lam):
+    """dL/dimage the GPU step used: the fused HIP loss (ggs_photometric_*) evaluated again on the step's own image."""
+    from ggsplat.loss import fused_photometric_loss
+    ci = pkg["render"].detach().clone().requires_grad_(True)
+    a, b = fused_photometric_loss(ci, gt.cuda(), mask.cuda(), lam)
+    (a + b).backward()
+    return ci.grad.cpu()
+
+
+def _chain(co, img, dimg, tensors, shapes, leaves):
+    """dL/dimage -> C oracle backward -> autograd through whatever produced the rasterizer inputs.
+    Stage-wise parity, every stage on IDENTICAL inputs (north_star): the loss stage is checked on its own -- the fused
+    loss gradient `dimg` against the host oracle's `img.grad`, <= 1e-4 -- and the rasterizer + binding chain consumes the
+    SAME `dimg` on both sides.  (Chaining the two oracles instead would compare position gradients that cancel to ~1 % of
+    their per-pixel terms under a smooth loss gradient against the un-cancelled response to the ~2e-6 fp32 noise between
+    two loss implementations: tools/dbg/fullsize_grad_noise.py.)
+    `leaves` already hold the gradients of the hinge terms; returns the oracle's raw gradients and, per leaf, the
+    element-wise magnitude |hinge part| + |photometric part| (the scale rounding errors are relative to: the two parts
+    can have opposite signs, e.g. on `_opacity`, and a ratio to their cancelled sum would measure the cancellation)."""
+    assert rel_l1(dimg, img.grad) <= REL_L1_TOL
+    hinge = [None if t.grad is None else t.grad.clone() for t in leaves]
+    g = co.backward(dimg.numpy())
+    keys = ("means3D", "scales", "rotations", "opacities", "shs")
+    torch.autograd.backward(list(tensors), [torch.from_numpy(g[k]).reshape(s) for k, s in zip(keys, shapes)])
+    scale = [t.grad.abs() if h is None else h.abs() + (t.grad - h).abs() for t, h in zip(leaves, hinge)]
+    return g, scale
+
+
+def _grad_err(gpu, ref, scale) -> float:
+    return float((gpu.detach().cpu().double() - ref.double()).abs().sum() / (scale.double().sum() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def skirt():
+    v, f = S.skirt_mesh()
+    cams = S.rig_cameras()
+    return v, f, cams
+
+
+def test_s3_form_full_size_against_the_oracle_pipeline(skirt):
+    from ggsplat.inner_step import DEFAULT_OPT, appearance_step
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    v, f, cams = skirt
+    P = f.shape[0]
+    opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "threshold_xyz": 0.002, "threshold_scale": 0.5})
+    params = S.skirt_gaussian_params(P, sh_degree=3)
+    g = torch.Generator().manual_seed(21)
+    params["_xyz"] = torch.randn(P, 3, generator=g) * 0.05
+    bc = torch.rand(P, 3, generator=g) + 0.05
+    bc = bc / bc.sum(1, keepdim=True)                                  # texel-bound: a barycentric point of the face
+    xyz_off = torch.randn(P, 3, generator=g) * 0.02                     # the "net" outputs (scene/avatar_net.py:82)
+    sh_off = torch.randn(P, 16, 3, generator=g) * 0.03
+    vis_mask = torch.rand(P, generator=g) > 0.5
+    gt, mask = _images(22)
+    bg = torch.tensor([0.0, 1.0, 0.0])                                  # the reference's green background
+    cam = _cam_to(cams[70], "cuda")
+
+    model = MeshGaussianModel.from_tensors(v, f, params, sh_degree=3, device="cuda", gs_bc=bc)
+    xo, so = xyz_off.clone().cuda().requires_grad_(True), sh_off.clone().cuda().requires_grad_(True)
+    out = appearance_step(model, lambda gm, c: (xo, so, vis_mask.cuda()), cam, gt.cuda(), mask.cuda(), bg.cuda(), opt=opt,
+                          fused_loss=True)
+    pkg = out["render_pkg"]
+    assert pkg["render"].shape == (3, H, W) and pkg["radii"].shape[0] == int(vis_mask.sum())
+
+    leaf = {n: params[n].clone().requires_grad_(True) for n in NAMES}
+    mv, xc, sc_ = v.clone().requires_grad_(True), xyz_off.clone().requires_grad_(True), sh_off.clone().requires_grad_(True)
+    local = leaf["_xyz"] + xc
+    xyz, scaling, rot = HO.mesh_bind(mv, f, params["binding"], local, leaf["_scaling"], leaf["_rotation"], bary=bc)
+    shs = torch.cat((leaf["_features_dc"], leaf["_features_rest"]), 1) + sc_
+    opacity = torch.sigmoid(leaf["_opacity"])
+    sel = [t[vis_mask] for t in (xyz, scaling, rot, opacity, shs)]      # gaussian_renderer/__init__.py:92-100
+    co, img = _c_render(cam, *_same_inputs(model, sel, vis_mask, final=True, shs=model.shs), 3, bg)
+    lam = opt.lambda_dssim
+    l_img = HO.l1_loss(img, gt, mask) * (1.0 - lam)
+    l_ssim = 1.0 - HO.ssim(img, gt, mask) * lam
+    l_xyz = F.relu(local.norm(dim=1) - opt.threshold_xyz).mean() * opt.lambda_xyz
+    l_sc = F.relu(torch.exp(leaf["_scaling"]) - opt.threshold_scale).norm(dim=1).mean() * opt.lambda_scale
+    l_op = F.relu(opt.threshold_opacity - opacity).mean() * opt.lambda_opacity
+    (l_img + l_ssim + l_xyz + l_sc + l_op).backward(retain_graph=True)
+    leaves = [leaf[n] for n in NAMES] + [mv, xc, sc_]
+    _, scale = _chain(co, img, _gpu_loss_grad(pkg, gt, mask, lam), sel, [t.shape for t in sel], leaves)
+
+    assert np.array_equal(pkg["radii"].cpu().numpy(), co.radii)
+    assert int((co.radii > 0).sum()) > 0.4 * P
+    assert rel_l1(pkg["render"], co.color) <= REL_L1_TOL
+    assert rel_l1(pkg["depth"], co.depth) <= REL_L1_TOL and rel_l1(pkg["alpha"], co.alpha) <= REL_L1_TOL
+    for k, r in (("img", l_img), ("ssim", l_ssim), ("xyz", l_xyz), ("scale", l_sc), ("opacity", l_op)):
+        assert abs(float(out[k]) - float(r)) <= 2e-5 * max(1.0, abs(float(r))), k
+    assert float(l_xyz) > 0 and float(l_sc) > 0 and float(l_op) > 0      # every hinge is active
+    gpu = [getattr(model, n).grad for n in NAMES] + [model.mesh.v.grad, xo.grad, so.grad]
+    for name, a, b, sc in zip(NAMES + ["mesh.v", "net.xyz_off", "net.sh_off"], gpu, leaves, scale):
+        assert _grad_err(a, b.grad, sc) <= REL_L1_TOL, name
+    # Gaussians that were masked out receive only the regulariser gradients
+    hidden = ~vis_mask
+    assert float(model._features_dc.grad.cpu()[hidden].abs().max()) == 0.0
+
+
+def test_s2_form_full_size_against_the_oracle_pipeline(skirt):
+    from ggsplat.inner_step import DEFAULT_OPT, registration_step
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    v, f, cams = skirt
+    P = f.shape[0]
+    opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "threshold_xyz": 0.002, "threshold_scale": 0.5})
+    params = S.skirt_gaussian_params(P, sh_degree=0)
+    params["_xyz"] = torch.randn(P, 3, generator=torch.Generator().manual_seed(31)) * 0.05
+    gt, mask = _images(32)
+    bg = torch.zeros(3)
+    cam = _cam_to(cams[13], "cuda")
+    model = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
+    model.training_setup(opt, is_ff=True)
+    out = registration_step(model, cam, gt.cuda(), mask.cuda(), bg.cuda(), opt=opt, optimizer_step=False, fused_loss=True)
+    pkg = out["render_pkg"]
+
+    leaf = {n: params[n].clone().requires_grad_(True) for n in NAMES}
+    mv = v.clone().requires_grad_(True)
+    xyz, scaling, rot = HO.mesh_bind(mv, f, params["binding"], leaf["_xyz"], leaf["_scaling"], leaf["_rotation"])
+    shs = torch.cat((leaf["_features_dc"], leaf["_features_rest"]), 1)
+    opacity = torch.sigmoid(leaf["_opacity"])
+    co, img = _c_render(cam, *_same_inputs(model, (xyz, scaling, rot, opacity, shs)), 0, bg)
+    vis = torch.from_numpy(co.radii > 0)
+    lam = opt.lambda_dssim
+    l_img = HO.l1_loss(img, gt, mask) * (1.0 - lam)
+    l_ssim = 1.0 - HO.ssim(img, gt, mask) * lam
+    l_xyz = F.relu(leaf["_xyz"][vis].norm(dim=1) - opt.threshold_xyz).mean() * opt.lambda_xyz
+    l_sc = F.relu(torch.exp(leaf["_scaling"][vis]) - opt.threshold_scale).norm(dim=1).mean() * opt.lambda_scale
+    (l_img + l_ssim + l_xyz + l_sc).backward(retain_graph=True)
+    leaves = [leaf[n] for n in NAMES if leaf[n].numel()] + [mv]
+    g, scale = _chain(co, img, _gpu_loss_grad(pkg, gt, mask, lam), (xyz, scaling, rot, opacity, shs),
+                      [xyz.shape, scaling.shape, rot.shape, opacity.shape, shs.shape], leaves)
+
+    assert np.array_equal(pkg["radii"].cpu().numpy(), co.radii)
+    assert rel_l1(pkg["render"], co.color) <= REL_L1_TOL
+    for k, r in (("img", l_img), ("ssim", l_ssim), ("xyz", l_xyz), ("scale", l_sc)):
+        assert abs(float(out[k]) - float(r)) <= 2e-5 * max(1.0, abs(float(r))), k
+    names = [n for n in NAMES if leaf[n].numel()] + ["mesh.v"]
+    gpu = [getattr(model, n).grad for n in names[:-1]] + [model.mesh.v.grad]
+    for name, a, b, sc in zip(names, gpu, leaves, scale):
+        assert _grad_err(a, b.grad, sc) <= REL_L1_TOL, name
+    assert rel_l1(pkg["viewspace_points"].grad, g["means2D"]) <= REL_L1_TOL
+    # densification statistics of this one view (scene/gaussian_model.py:410-412)
+    ref = torch.zeros(P, 1)
+    ref[vis] = torch.from_numpy(g["means2D"])[vis, :2].norm(dim=-1, keepdim=True)
+    assert rel_l1(model.xyz_gradient_accum, ref) <= REL_L1_TOL
+    assert torch.equal(model.denom.cpu().squeeze(1) > 0, vis)
+
+
+def _close(a, b, what, rtol=1e-4, atol=2e-6):
+    """Same kernels on both sides; only the order of the float atomics differs, and Adam(eps=1e-15) turns a gradient
+    whose sign is rounding noise into a full +-lr step: require 99.5 % of a tensor within tolerance + a tiny mean."""
+    ok = (a - b).abs() <= atol + rtol * b.abs()
+    assert float(ok.float().mean()) >= 0.995, (what, float(ok.float().mean()), float((a - b).abs().max()))
+    assert float((a - b).abs().mean()) <= 1e-5, (what, float((a - b).abs().mean()))
+
+
+def test_graphed_registration_step_full_size(skirt):
+    """GraphedRegistrationStep(lean) at 100k / 1080p: three replayed iterations on three cameras against the eager
+    registration_step + torch.optim.Adam -- loss terms, post-Adam parameters, mesh.v, densification statistics."""
+    from ggsplat import rasterizer as R
+    from ggsplat.adam import GraphAdam
+    from ggsplat.inner_step import DEFAULT_OPT, GraphedRegistrationStep, registration_step
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    v, f, cams = skirt
+    P = f.shape[0]
+    opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "threshold_xyz": 0.002, "threshold_scale": 0.5})
+    params = S.skirt_gaussian_params(P, sh_degree=0)
+    params["_xyz"] = torch.randn(P, 3, generator=torch.Generator().manual_seed(41)) * 0.05
+    bg = torch.zeros(3, device="cuda")
+    sides = []
+    for graph in (False, True):
+        m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
+        m.training_setup(opt, is_ff=True)
+        if graph:
+            m.optimizer = GraphAdam(m.optimizer.param_groups, lr=0.0, eps=1e-15)
+        sides.append(m)
+    eager, graphed = sides
+    R._cap_hint.clear()
+    step = GraphedRegistrationStep(graphed, W, H, bg, opt=opt, lean=True)
+    for it, ci in enumerate((5, 90, 155)):
+        cam = _cam_to(cams[ci], "cuda")
+        gt, mask = (t.cuda() for t in _images(50 + it))
+        ref = registration_step(eager, cam, gt, mask, bg, opt=opt, fused_loss=True)
+        out = step(cam, gt, mask)
+        for k in ("img", "ssim", "xyz", "scale", "loss"):
+            r = float(ref[k].detach())
+            assert abs(float(out[k]) - r) <= 1e-4 * max(1.0, abs(r)), (it, k)
+    assert graphed.optimizer.step_count == 3
+    for n in ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation"):
+        _close(getattr(graphed, n).detach(), getattr(eager, n).detach(), n)
+        assert float((getattr(graphed, n).detach().cpu() - params[n]).abs().max()) > 0, n       # ... and it did train
+    _close(graphed.mesh.v.detach(), eager.mesh.v.detach(), "mesh.v")
+    _close(graphed.xyz_gradient_accum, eager.xyz_gradient_accum, "xyz_gradient_accum", rtol=1e-3, atol=1e-7)
+    assert torch.equal(graphed.denom, eager.denom) and torch.equal(graphed.max_radii2D, eager.max_radii2D)
+
+
+def test_graphed_appearance_step_full_size(skirt):
+    """GraphedAppearanceStep at config-4 size (100k texel-bound Gaussians, K = 16, ~50 % visible, 1080p): the mask is
+    applied to the opacities inside the captured step; the eager side gathers the visible Gaussians like the reference."""
+    from ggsplat import rasterizer as R
+    from ggsplat.adam import GraphAdam
+    from ggsplat.inner_step import DEFAULT_OPT, GraphedAppearanceStep, appearance_step
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    v, f, cams = skirt
+    P = f.shape[0]
+    opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "threshold_xyz": 0.002, "threshold_scale": 0.5})
+    params = S.skirt_gaussian_params(P, sh_degree=3)
+    g = torch.Generator().manual_seed(61)
+    bc = torch.rand(P, 3, generator=g) + 0.05
+    bc = bc / bc.sum(1, keepdim=True)
+    vis = (torch.rand(P, generator=g) > 0.5).cuda()
+    bg = torch.tensor([0.0, 1.0, 0.0], device="cuda")
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            gg = torch.Generator().manual_seed(62)
+            self.xyz_off = torch.nn.Parameter((torch.randn(P, 3, generator=gg) * 0.02).cuda())
+            self.sh_off = torch.nn.Parameter((torch.randn(P, 16, 3, generator=gg) * 0.03).cuda())
+
+        def forward(self, gaussians, cam):
+            return self.xyz_off, self.sh_off, vis
+
+    sides = []
+    for graph in (False, True):
+        m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=3, device="cuda", gs_bc=bc)
+        net = Net()
+        groups = [{"params": [net.xyz_off], "lr": 1e-4, "name": "net_xyz"}, {"params": [net.sh_off], "lr": 2e-3, "name": "net_sh"},
+                  {"params": [m._opacity], "lr": 1e-2, "name": "opacity"}, {"params": [m._scaling], "lr": 2e-3, "name": "scaling"},
+                  {"params": [m._features_dc], "lr": 2.5e-3, "name": "f_dc"}]
+        o = GraphAdam(groups, lr=0.0, eps=1e-15) if graph else torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        sides.append((m, net, o))
+    (me, ne, oe), (mg, ng, og) = sides
+    R._cap_hint.clear()
+    step = GraphedAppearanceStep(mg, ng, W, H, bg, og, opt=opt)
+    for it, ci in enumerate((40, 120)):
+        cam = _cam_to(cams[ci], "cuda")
+        gt, mask = (t.cuda() for t in _images(70 + it))
+        ref = appearance_step(me, ne, cam, gt, mask, bg, optimizer=oe, opt=opt, fused_loss=True)
+        out = step(cam, gt, mask)
+        for k in ("img", "ssim", "xyz", "scale", "opacity", "loss"):
+            r = float(ref[k].detach())
+            assert abs(float(out[k]) - r) <= 1e-4 * max(1.0, abs(r)), (it, k)
+    assert step.recaptures == 0 and og.step_count == 2
+    _close(ng.xyz_off.detach(), ne.xyz_off.detach(), "net.xyz_off")
+    _close(ng.sh_off.detach(), ne.sh_off.detach(), "net.sh_off")
+    for n in ("_opacity", "_scaling", "_features_dc"):
+        _close(getattr(mg, n).detach(), getattr(me, n).detach(), n)

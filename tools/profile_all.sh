@@ -16,6 +16,11 @@ BENCH="python $R/bench.py --cpu-views 0 --loop-views 0 $*"
 python -c "import sys; sys.path.insert(0, '$R/gaussian-garments_amd'); from ggsplat import _lib; print(_lib.build_id())" > ${OUT}_build_id.txt
 echo "$*" > ${OUT}_args.txt
 timeout 600 rocprofv3 --kernel-trace --stats -d ${OUT}_trace -o t -- $BENCH --steps 3 --warmup 1 > ${OUT}_trace.log 2>&1 || echo "trace pass failed" >> ${OUT}_trace.log
+if [ -n "$ONLY_TRACE" ]; then
+  find ${OUT}_trace -type f ! -name '*.db' -delete 2>/dev/null || true
+  grep -h '^{' ${OUT}_trace.log | tail -1 > ${OUT}_bench.json || true
+  exit 0
+fi
 PMC="$BENCH --steps 1 --warmup 0 --views 32"
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d ${OUT}_sq -o s -- $PMC > ${OUT}_sq.log 2>&1 || echo "sq pass failed" >> ${OUT}_sq.log
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d ${OUT}_fetch -o f -- $PMC > ${OUT}_fetch.log 2>&1 || echo "fetch pass failed" >> ${OUT}_fetch.log
