@@ -104,11 +104,15 @@ int check_modes(const GgsParams* p, const void* shs, const void* colors, const v
     return GGS_OK;
 }
 
-// View-loop splits of the per-Gaussian backward: ~8k waves keep 256 CUs busy.
+// View-loop splits of the per-Gaussian backward: ~4k waves (4 per SIMD) keep 256 CUs busy.  (Tuning knob: GGS_BWD_WAVES.)
 int bwd_splits(const GgsParams* p) {
     if (p->P <= 0) return 1;
+    static const int target = [] {
+        const char* e = getenv("GGS_BWD_WAVES");
+        return e && *e ? atoi(e) : 4096;    // measured: 4096 beats 8192 and 2048 at K = 1 and K = 16 (tools/dbg/sweep_bwd_waves.sh)
+    }();
     const int waves = (p->P + 63) / 64;
-    int s = (8192 + waves - 1) / waves;
+    int s = (target + waves - 1) / waves;
     return s < 1 ? 1 : (s > p->n_views ? p->n_views : s);
 }
 
@@ -415,8 +419,8 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
             default: hipLaunchKernelGGL(ggs_k_preprocess_bwd_sh3, grid, dim3(256), 0, s, a); break;
         }
         if (splits > 1) {
-            const size_t n = (size_t)(14 + 3 * p->K) * p->P;
-            hipLaunchKernelGGL(ggs_k_reduce_partials, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, splits);
+            const size_t lds = (size_t)64 * (14 + 3 * p->K + 1) * sizeof(float);      // 64 Gaussians x all components
+            hipLaunchKernelGGL(ggs_k_reduce_partials, dim3((unsigned)((p->P + 63) / 64)), dim3(256), lds, s, a, splits);
         }
         prof_stop(K_PRE_BWD, s);
         GGS_TRY(check("preprocess_bwd", s, p->debug));

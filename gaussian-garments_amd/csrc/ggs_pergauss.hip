@@ -540,17 +540,33 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess_bwd_sh1(PreBwdArgs a) { 
 __global__ __launch_bounds__(256) void ggs_k_preprocess_bwd_sh2(PreBwdArgs a) { preprocess_bwd_body<2>(a); }
 __global__ __launch_bounds__(256) void ggs_k_preprocess_bwd_sh3(PreBwdArgs a) { preprocess_bwd_body<3>(a); }
 
-// K6b: grid ceil(P * NC / 256).  Sums the per-split partials part[s][c][g] into the gradient tensors.
+// K6b: grid ceil(P / 64), block 256.  Sums the per-split partials part[s][c][g] into the gradient tensors.
+// The partials are component-major (coalesced writes of the per-Gaussian kernel, coalesced reads here: 64 consecutive
+// Gaussians of one component = 256 B), the gradient tensors are Gaussian-major ([P,3], [P,4], [P,K,3]): a block sums 64
+// Gaussians x all components into an LDS tile and writes it back with the component index fastest, so the SH block of a
+// Gaussian (3K consecutive floats) leaves as contiguous runs.  (One thread per (component, Gaussian) with the Gaussian
+// fastest wrote 4 bytes every 12K bytes: 0.6 TB/s at K = 16, profiles/r02a_c5_kernel_stats.md.)
+#define GGS_RP_G 64
 __global__ __launch_bounds__(256) void ggs_k_reduce_partials(PreBwdArgs a, int splits) {
-    const int NC = 14 + 3 * a.K;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)NC * a.P) return;
-    const int c = (int)(idx / a.P), g = (int)(idx % a.P);
-    float* dst = ggs_grad_slot(a, c, g);
-    if (!dst) return;
+    extern __shared__ float s_tile[];                       // [GGS_RP_G][NC + 1]
+    const int NC = 14 + 3 * a.K, LD = NC + 1;
+    const int g0 = blockIdx.x * GGS_RP_G;
+    const int gl = threadIdx.x & (GGS_RP_G - 1), cl = threadIdx.x / GGS_RP_G;      // 4 component lanes of 64 Gaussians
     const int nk3 = a.colors ? 0 : 3 * (a.deg + 1) * (a.deg + 1);
-    float sum = 0.f;
-    if (c < 14 + nk3)                            // SH coefficients above the active degree were never written
-        for (int s = 0; s < splits; ++s) sum += a.part[((size_t)s * NC + c) * a.P + g];
-    if (a.accumulate) *dst += sum; else *dst = sum;
+    const bool in = g0 + gl < a.P;
+    for (int c = cl; c < NC; c += 256 / GGS_RP_G) {
+        float sum = 0.f;
+        if (in && c < 14 + nk3)                             // SH coefficients above the active degree were never written
+            for (int s = 0; s < splits; ++s) sum += a.part[((size_t)s * NC + c) * a.P + g0 + gl];
+        s_tile[gl * LD + c] = sum;
+    }
+    __syncthreads();
+    const int n = min(GGS_RP_G, a.P - g0) * NC;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int g = i / NC, c = i - g * NC;
+        float* dst = ggs_grad_slot(a, c, g0 + g);
+        if (!dst) continue;
+        const float sum = s_tile[g * LD + c];
+        if (a.accumulate) *dst += sum; else *dst = sum;
+    }
 }

@@ -44,6 +44,8 @@ _SIGS = {
     "ggs_photometric_backward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 7),
     "ggs_dist2_3nn": (C.c_int, [C.c_int, _PTR, _PTR, _PTR]),
     "ggs_fused_bias_act": (C.c_int, [C.c_size_t, _PTR, _PTR, _PTR, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _PTR, _PTR]),
+    "ggs_fused_bias_act_t": (C.c_int, [C.c_int, C.c_size_t, _PTR, _PTR, _PTR, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _PTR, _PTR]),
+    "ggs_upfirdn2d_t": (C.c_int, [C.c_int] * 5 + [_PTR, _PTR] + [C.c_int] * 10 + [_PTR, _PTR]),
     "ggs_upfirdn2d_out_size": (C.c_int, [C.c_int] * 12 + [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ggs_upfirdn2d": (C.c_int, [C.c_int] * 4 + [_PTR, _PTR] + [C.c_int] * 10 + [_PTR, _PTR]),
     "ggs_adam_state_bytes": (C.c_size_t, []),
@@ -113,3 +115,13 @@ def source_hash() -> str:
 
 def build_id() -> str:
     return lib().ggs_build_id().decode()
+
+
+def dtype_code(dt) -> int:
+    """GGS_DTYPE_* of a torch dtype for the typed StyleGAN-op entry points; anything but float / half / double raises
+    like the upstream dispatch macro does."""
+    import torch
+    try:
+        return {torch.float32: 0, torch.float16: 1, torch.float64: 2}[dt]
+    except KeyError:
+        raise RuntimeError(f'"ggsplat stylegan op" not implemented for \'{str(dt).replace("torch.", "")}\'') from None

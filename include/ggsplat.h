@@ -196,7 +196,19 @@ int ggs_dist2_3nn(int P, const float* points, float* out, void* stream);
  *   ggs_upfirdn2d: input [major][in_h][in_w][minor], kernel [kh][kw] -> out [major][out_h][out_w][minor]
  *       (upsample by zero insertion, pad (negative = crop), convolve, decimate);
  *       out_h = (in_h up_y + pad_y0 + pad_y1 - kh + down_y) / down_y, likewise out_w (ggs_upfirdn2d_out_size).
+ * The `_t` entry points take the element type of every buffer (x, bias, ref, y / input, kernel, out): the reference
+ * dispatches float, double and half (AT_DISPATCH_FLOATING_TYPES_AND_HALF: fused_bias_act_kernel.cu:96,
+ * upfirdn2d_kernel.cu:340-369); half accumulates in float, double in double, nothing is converted on the way in or out.
+ * The un-suffixed entry points are the float forms.
  */
+#define GGS_DTYPE_F32 0
+#define GGS_DTYPE_F16 1
+#define GGS_DTYPE_F64 2
+int ggs_fused_bias_act_t(int dtype, size_t n, const void* x, const void* bias, const void* ref, int step_b, int size_b,
+                         int act, int grad, float alpha, float scale, void* y, void* stream);
+int ggs_upfirdn2d_t(int dtype, int major, int in_h, int in_w, int minor, const void* input, const void* kernel, int kh,
+                    int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_x1, int pad_y0, int pad_y1,
+                    void* out, void* stream);
 int ggs_fused_bias_act(size_t n, const float* x, const float* bias, const float* ref, int step_b, int size_b,
                        int act, int grad, float alpha, float scale, float* y, void* stream);
 int ggs_upfirdn2d_out_size(int in_h, int in_w, int kh, int kw, int up_x, int up_y, int down_x, int down_y, int pad_x0,

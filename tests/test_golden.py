@@ -167,3 +167,20 @@ def test_lr_schedule_matches_reference(name):
     f = get_expon_lr_func(float(lr_init), float(lr_final), int(delay_steps), float(delay_mult), int(max_steps))
     got = np.array([f(int(t)) for t in d["steps"]])
     assert np.allclose(got, d[name], rtol=1e-12, atol=0.0)
+
+
+def test_stylegan_oracle_matches_reference_native_paths():
+    """oracle/stylegan_oracle.py (the checker of the full-size StyleUNet-shape GPU tests) against the goldens produced
+    by the reference's own upfirdn2d_native / fused_leaky_relu CPU paths."""
+    from oracle import stylegan_oracle as SO
+    d = _load("stylegan_ops.npz")
+    x, b = torch.tensor(d["act_x"]), torch.tensor(d["act_b"])
+    assert np.allclose(SO.fused_leaky_relu(x, b).numpy(), d["act_y_bias"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(SO.fused_leaky_relu(x, None).numpy(), d["act_y_nobias"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(SO.fused_leaky_relu(torch.tensor(d["act2_x"]), torch.tensor(d["act2_b"])).numpy(), d["act2_y"], rtol=1e-6, atol=1e-7)
+    inp = torch.tensor(d["ufd_in"])
+    for name in ("blur", "blur3", "up2", "up2haar", "down2", "down2haar", "crop", "mixed"):
+        ux, uy, dx, dy, px0, px1, py0, py1 = [int(v) for v in d[f"ufd_{name}_cfg"]]
+        out = SO.upfirdn2d(inp, torch.tensor(d[f"ufd_{name}_k"]), (ux, uy), (dx, dy), (px0, px1, py0, py1))
+        assert out.shape == d[f"ufd_{name}_out"].shape, name
+        assert np.allclose(out.numpy(), d[f"ufd_{name}_out"], rtol=1e-5, atol=1e-6), name

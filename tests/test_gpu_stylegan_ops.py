@@ -81,3 +81,82 @@ def test_upfirdn2d_adjoint_identity_and_minor():
     for c in range(3):
         oc = U.upfirdn2d(xm[..., c:c + 1].contiguous(), k, 1, 1, 1, 1, 1, 1, 2, 0)
         assert torch.equal(om[..., c:c + 1], oc)
+
+
+# ---- the StyleUNet shapes (minor = 1, major = batch x channels) through the tiled specialised kernels ---------------
+def _k4():
+    k = torch.tensor([1.0, 3.0, 3.0, 1.0])
+    k = k[None, :] * k[:, None]
+    return k / k.sum()
+
+
+def _haar():
+    s = 1 / (2 ** 0.5)
+    l, h = torch.tensor([[s, s]]), torch.tensor([[-s, s]])
+    return {"ll": l.T * l, "lh": h.T * l, "hl": l.T * h, "hh": h.T * h}       # styleunet.py:371-384
+
+
+# (name, kernel, up, down, pad) -- Blur of a stride-2 ConvLayer (pad (2,2)) and of an upsampling ModulatedConv2d (pad (1,1),
+# kernel * 4), Upsample / Downsample (styleunet.py:32-71), Haar / inverse Haar (:387-425), and the backward forms the
+# reference's autograd wrapper issues for them (up <-> down, flipped kernel, g_pad: upfirdn2d.py:128-141)
+STYLE_CASES = [
+    ("blur_pad22", _k4(), 1, 1, (2, 2, 2, 2)), ("blur_pad11_x4", _k4() * 4, 1, 1, (1, 1, 1, 1)), ("blur_pad21", _k4(), 1, 1, (2, 1, 2, 1)),
+    ("upsample", _k4() * 4, 2, 1, (2, 1, 2, 1)), ("downsample", _k4(), 1, 2, (1, 1, 1, 1)),
+    ("haar_ll", _haar()["ll"], 1, 2, (0, 0, 0, 0)), ("haar_hl", _haar()["hl"], 1, 2, (0, 0, 0, 0)),
+    ("ihaar_lh", _haar()["lh"], 2, 1, (1, 0, 1, 0)), ("ihaar_hh", _haar()["hh"], 2, 1, (1, 0, 1, 0)),
+    ("upsample_bwd", torch.flip(_k4() * 4, [0, 1]), 1, 2, (1, 2, 1, 2)), ("downsample_bwd", torch.flip(_k4(), [0, 1]), 2, 1, (2, 2, 2, 2)),
+    ("crop_blur", _k4(), 1, 1, (-3, 2, 1, -5)),
+]
+
+
+@pytest.mark.parametrize("case", STYLE_CASES, ids=[c[0] for c in STYLE_CASES])
+@pytest.mark.parametrize("shape", [(2, 8, 512, 512), (1, 3, 2048, 2048), (3, 5, 130, 77)], ids=["512", "2048", "ragged"])
+def test_upfirdn2d_styleunet_shapes(case, shape):
+    import upfirdn2d as U
+    from oracle import stylegan_oracle as SO
+    name, k, up, down, pad = case
+    B, Cn, Hh, Ww = shape
+    g = torch.Generator().manual_seed(hash(name) % 1000)
+    x = torch.randn(B, Cn, Hh, Ww, generator=g).cuda()
+    out = U.upfirdn2d(x.reshape(-1, Hh, Ww, 1), k.cuda(), up, up, down, down, *pad)
+    ref = SO.upfirdn2d(x, k.cuda(), (up, up), (down, down), pad)
+    assert tuple(out.shape) == (B * Cn, ref.shape[2], ref.shape[3], 1)
+    err = float((out.view_as(ref) - ref).abs().max())
+    assert err <= 2e-6 * max(1.0, float(ref.abs().max())), (name, err)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.float64, 1e-13)])
+def test_stylegan_ops_native_dtypes(dtype, tol):
+    """half and double are processed in place of being converted: output dtype = input dtype, double keeps double
+    accuracy (a float round trip would leave ~1e-7), half matches a float computation rounded once."""
+    import fused
+    import upfirdn2d as U
+    from oracle import stylegan_oracle as SO
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 6, 96, 80, generator=g, dtype=torch.float64)
+    b = torch.randn(6, generator=g, dtype=torch.float64)
+    xd, bd = x.to(dtype).cuda(), b.to(dtype).cuda()
+    e = xd.new_empty(0)
+    # alpha and scale cross the ABI as C floats (upstream's op signature has `float alpha, float scale` too)
+    a32, s32 = float(torch.tensor(0.2, dtype=torch.float32)), float(torch.tensor(SQRT2, dtype=torch.float32))
+    y = fused.fused_bias_act(xd, bd, e, 3, 0, 0.2, SQRT2)
+    ref = SO.fused_leaky_relu(xd.double(), bd.double(), a32, s32)
+    assert y.dtype == dtype and float((y.double() - ref).abs().max()) <= tol * float(ref.abs().max())
+    gi = fused.fused_bias_act(xd, e, y, 3, 1, 0.2, SQRT2)            # derivative mode with a reference tensor
+    refg = torch.where(ref > 0, xd.double(), xd.double() * a32) * s32
+    assert gi.dtype == dtype and float((gi.double() - refg).abs().max()) <= tol * float(refg.abs().max())
+    for name, k, up, down, pad in STYLE_CASES[:6] + [("generic", torch.randn(3, 2, generator=g), 1, 1, (1, 0, 2, 0))]:
+        out = U.upfirdn2d(xd.reshape(-1, 96, 80, 1), k.to(dtype).cuda(), up, up, down, down, *pad)
+        r = SO.upfirdn2d(xd.double(), k.to(dtype).double().cuda(), (up, up), (down, down), pad)
+        assert out.dtype == dtype
+        assert float((out.view_as(r).double() - r).abs().max()) <= tol * max(1.0, float(r.abs().max())), name
+
+
+def test_stylegan_ops_reject_other_dtypes():
+    import fused
+    import upfirdn2d as U
+    x = torch.zeros(1, 2, 4, 4, device="cuda", dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="not implemented for"):
+        fused.fused_bias_act(x, x.new_empty(0), x.new_empty(0), 3, 0, 0.2, 1.0)
+    with pytest.raises(RuntimeError, match="not implemented for"):
+        U.upfirdn2d(x.reshape(2, 4, 4, 1), torch.ones(2, 2, device="cuda"), 1, 1, 1, 1, 0, 0, 0, 0)
