@@ -248,7 +248,7 @@ def main():
             P_vis = float((radii > 0).sum().item()) / chunk
             N_chunk = st.num_rendered
             # blended splats per pixel (n_contrib = position of the last contributor in the tile's list)
-            nc = st.img[st.img.numel() // 2:].view(torch.int32)[:chunk * H * W]
+            nc = R.img_sections(st)["n_contrib"]
             mean_contrib = float(nc.float().mean().item())
             del st
         L.ggs_profile_enable(0)

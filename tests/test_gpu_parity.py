@@ -168,7 +168,7 @@ def test_internals_bit_exact():
     # Index output of the compositing: the LAST CONTRIBUTOR of every pixel.  n_contrib is a 1-based position in the
     # tile's list -- the culled list here, the full list in the oracle -- so the comparable quantity is the Gaussian id
     # found at that position: it must be the same Gaussian, pixel for pixel (and 0 contributors in the same pixels).
-    n_hip = img[st.img.numel() // 2:][:HW * 4].view(torch.int32).reshape(120, 160).numpy().astype(np.int64)
+    n_hip = R.img_sections(st)["n_contrib"][0].cpu().numpy().astype(np.int64)
     n_ref = it["n_contrib"].astype(np.int64)
     ty, tx = np.meshgrid(np.arange(120) // 16, np.arange(160) // 16, indexing="ij")
     tile = ty * gx + tx

@@ -22,7 +22,7 @@ if [ -n "$ONLY_TRACE" ]; then
   rm -rf ${OUT}_trace
   exit 0
 fi
-PMC="$BENCH --steps 1 --warmup 0 --views 32"
+PMC="$BENCH --steps 1 --warmup 0 --views ${PMC_VIEWS:-32}"
 timeout 600 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --kernel-trace -d ${OUT}_sq -o s -- $PMC > ${OUT}_sq.log 2>&1 || echo "sq pass failed" >> ${OUT}_sq.log
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d ${OUT}_fetch -o f -- $PMC > ${OUT}_fetch.log 2>&1 || echo "fetch pass failed" >> ${OUT}_fetch.log
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d ${OUT}_write -o w -- $PMC > ${OUT}_write.log 2>&1 || echo "write pass failed" >> ${OUT}_write.log

@@ -69,7 +69,7 @@ def main(tag, prefix, workload):
                  f"--loop-views 0 {bargs} --steps 1 --warmup 0 --views 32`; wave-cycle counters are in quad-cycles.\n\n")
     fe, wr = db(tag, "fetch"), db(tag, "write")
     if fe and wr:
-        hbm_summary.main(fe, wr, prefix + "_hbm_traffic", 32, bid, workload)
+        hbm_summary.main(fe, wr, prefix + "_hbm_traffic", int(os.environ.get("PMC_VIEWS", "32")), bid, workload)
     b = os.path.join(g, f"{tag}_bench.json")
     if os.path.exists(b) and os.path.getsize(b) > 2:
         shutil.copy(b, prefix + "_bench_profiled.json")

@@ -17,9 +17,7 @@ for vi in (0, 40, 100, 159):
     sec = R.bin_sections(st)
     cnt = sec["tile_count"][0].cpu().numpy().astype(np.int64)
     HW = 1920 * 1080
-    img = st.img
-    half = img.numel() // 2
-    ncon = img[half:half + HW * 4].view(torch.int32).reshape(1080, 1920)
+    ncon = R.img_sections(st)["n_contrib"][0]
     nc = torch.nn.functional.pad(ncon, (0, 0, 0, 8))  # H 1080 -> 1088
     tmax = nc.reshape(68, 16, 120, 16).permute(0, 2, 1, 3).reshape(68 * 120, 256).max(1).values.cpu().numpy()
     act = cnt > 0
