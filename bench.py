@@ -189,7 +189,19 @@ def main():
     sync()
 
     def overflowed():
-        return any(int(h[1].item()) != 0 for h in graph["headers"])
+        """Did a captured forward overflow its binning capacity on ANY rank?  The answer steers extra step() calls, which
+        contain the all-reduce: every rank must take the same branch, so the flag itself is reduced (max) over the ranks."""
+        mine = any(int(h[1].item()) != 0 for h in graph["headers"])
+        if world > 1:
+            f = torch.tensor([1.0 if mine else 0.0], device=dev)
+            dist.all_reduce(f, op=dist.ReduceOp.MAX)
+            mine = bool(f.item() > 0)
+        return mine
+    if world > 1:                            # a capture that failed on one rank only: everybody launches eagerly
+        f = torch.tensor([1.0 if graph["g"] is None else 0.0], device=dev)
+        dist.all_reduce(f, op=dist.ReduceOp.MAX)
+        if f.item() > 0:
+            graph.update(g=None, grads=None, headers=[])
     if graph["g"] is not None and (args.warmup == 0 or overflowed()):
         if args.warmup == 0:
             step()

@@ -423,30 +423,31 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
                 const float Gr = __builtin_amdgcn_exp2f(power);
                 const float ar = __builtin_fminf(GGS_ALPHA_MAX, op * Gr);
                 const bool valid = (pos < nc[q]) & (power <= 0.f) & (ar >= GGS_ALPHA_MIN);
-                // predication instead of branches: a lane that did not blend this splat carries
-                // alpha = G = 0, which zeroes every contribution and leaves (T, B) unchanged.
-                const float alpha = valid ? ar : 0.f;
-                const float G = valid ? Gr : 0.f;
-                const float ra = __builtin_amdgcn_rcpf(1.f - alpha);
-                T[q] *= ra;                               // transmittance in front of this splat
-                const float w = alpha * T[q];
-                float sdot = fmaf(cb, dC2[q], fmaf(cg, dC1[q], cr * dC0[q]));
-                if (DA) sdot += fmaf(dep, dD[q], dA[q]);
-                const float dL_da = fmaf(T[q], sdot, -B[q] * ra);
-                B[q] = fmaf(w, sdot, B[q]);
-                v_r = fmaf(w, dC0[q], v_r); v_g = fmaf(w, dC1[q], v_g); v_b = fmaf(w, dC2[q], v_b);
-                if (DA) v_dep = fmaf(w, dD[q], v_dep);
+                // Lanes that did not blend this splat sit out (EXEC mask): their (T, B) and sums keep their values, and a
+                // quadrant nobody blended skips the block on the scalar branch.  (The select form -- alpha = G = 0 in those
+                // lanes -- costs two v_cndmask per quadrant: -2.3 % kernel time, tools/dbg/ab_libs.sh.)
                 // Geometry terms are accumulated as RAW moments of h = G dL/dG over the pixels
                 //   (sum h, sum h dx, sum h dy, sum h dx^2, sum h dx dy, sum h dy^2);
                 // the per-splat constants (conic, opacity, -1/2) are applied once per Gaussian in the
                 // per-Gaussian backward instead of once per pixel here (straight through the 0.99 clamp).
-                const float t = G * dL_da;
-                v_op += t;                                   // = sum G dL/dalpha  (d/d opacity)
-                const float hx = t * dx, hy = t * dy;        // the common factor `opacity` is applied later
-                v_mx += hx; v_my += hy;
-                v_cx = fmaf(hx, dx, v_cx);
-                v_cy = fmaf(hx, dy, v_cy);
-                v_cz = fmaf(hy, dy, v_cz);
+                if (valid) {
+                    const float ra = __builtin_amdgcn_rcpf(1.f - ar);
+                    T[q] *= ra;
+                    const float w = ar * T[q];
+                    float sdot = fmaf(cb, dC2[q], fmaf(cg, dC1[q], cr * dC0[q]));
+                    if (DA) sdot += fmaf(dep, dD[q], dA[q]);
+                    const float dL_da = fmaf(T[q], sdot, -B[q] * ra);
+                    B[q] = fmaf(w, sdot, B[q]);
+                    v_r = fmaf(w, dC0[q], v_r); v_g = fmaf(w, dC1[q], v_g); v_b = fmaf(w, dC2[q], v_b);
+                    if (DA) v_dep = fmaf(w, dD[q], v_dep);
+                    const float t = Gr * dL_da;
+                    v_op += t;
+                    const float hx = t * dx, hy = t * dy;
+                    v_mx += hx; v_my += hy;
+                    v_cx = fmaf(hx, dx, v_cx);
+                    v_cy = fmaf(hx, dy, v_cy);
+                    v_cz = fmaf(hy, dy, v_cz);
+                }
             }
             // rows of Q1 = (mx, cx, my, cy), of Q2 = (cz, r, op, g); R5 = b in every row (DA: b, b, depth, depth)
             const float Q1 = swap16_add(swap32_add(v_mx, v_my), swap32_add(v_cx, v_cy));

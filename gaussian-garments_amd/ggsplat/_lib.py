@@ -13,7 +13,8 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below: one HIP runtime per process)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "libggsplat.so"))
+# GGS_LIB_PATH: load another build of the same library (A/B timing of kernel variants, tools/dbg/ab_libs.sh)
+LIB_PATH = os.environ.get("GGS_LIB_PATH") or os.path.normpath(os.path.join(_HERE, "..", "csrc", "libggsplat.so"))
 
 
 class GgsParams(C.Structure):
@@ -107,7 +108,7 @@ def source_hash() -> str:
     """The id `make` would bake into a library built from the sources on disk now (csrc/Makefile SRC_HASH)."""
     import hashlib
     h = hashlib.sha256()
-    d = os.path.dirname(LIB_PATH)
+    d = os.path.normpath(os.path.join(_HERE, "..", "csrc"))
     for name in _SRC_ORDER:
         with open(os.path.join(d, name), "rb") as f:
             h.update(f.read())
