@@ -23,6 +23,28 @@
 
 namespace {
 
+// Empty tile (~90 % of the tiles of a view) fully inside the image: nothing to composite, the wave only stores the
+// background.  Lane l owns 4 consecutive pixels of row l / 4, so each of the 7 planes leaves as ONE 16-byte store per lane
+// (16 rows x 64 contiguous bytes) instead of four 4-byte stores in the quadrant layout.  Where most of a launch is background
+// (config 5: 4K frames) the forward is bound by exactly these stores.  Returns false when the tile must take the general path
+// (image edge, row pitch not a multiple of 16 bytes).
+__device__ __forceinline__ bool store_empty_tile(const RenderArgs& a, int v, int ox, int oy, int lane) {
+    if ((a.W & 3) != 0 || ox + GGS_TILE > a.W || oy + GGS_TILE > a.H) return false;
+    const size_t HW = (size_t)a.H * a.W;
+    const size_t pix = (size_t)(oy + (lane >> 2)) * a.W + ox + (lane & 3) * 4;
+    const float* bg = a.bg + 3 * v;
+    float* oc = a.out_color + (size_t)v * 3 * HW + pix;
+    const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
+    *reinterpret_cast<float4*>(oc) = make_float4(b0, b0, b0, b0);
+    *reinterpret_cast<float4*>(oc + HW) = make_float4(b1, b1, b1, b1);
+    *reinterpret_cast<float4*>(oc + 2 * HW) = make_float4(b2, b2, b2, b2);
+    *reinterpret_cast<float4*>(a.out_depth + (size_t)v * HW + pix) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(a.out_alpha + (size_t)v * HW + pix) = make_float4(0.f, 0.f, 0.f, 0.f);
+    *reinterpret_cast<float4*>(a.final_T + (size_t)v * HW + pix) = make_float4(1.f, 1.f, 1.f, 1.f);
+    *reinterpret_cast<uint4*>(a.n_contrib + (size_t)v * HW + pix) = make_uint4(0, 0, 0, 0);
+    return true;
+}
+
 // K4b body.  NQ = 4: one wave per tile, lane = 4 pixels (one per quadrant) -- the throughput mapping.
 // (The latency mapping for launches too small to fill the chip -- one wave per (tile, quadrant), grid 4x larger:
 // a single view has ~1.1k non-empty tiles of ~300 splats for 1024 SIMDs and is bounded by the serial walk of its
@@ -43,6 +65,8 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
     const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
     uint32_t* ids = a.ids + base;
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
+
+    if (L == 0 && store_empty_tile(a, v, ox, oy, lane)) return;
 
     float pxf[NQ], pyf[NQ], T[NQ], C0[NQ], C1[NQ], C2[NQ], D[NQ], A[NQ];
     uint32_t last[NQ];
@@ -160,6 +184,12 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
     uint32_t* ids = a.ids + base;
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
     const float inf_v = __builtin_inff();
+    if (L == 0) {                 // empty tile: the wave of quadrant 0 stores the whole tile, the other three have nothing to do
+        if ((a.W & 3) == 0 && tx * GGS_TILE + GGS_TILE <= a.W && ty * GGS_TILE + GGS_TILE <= a.H) {
+            if (q0 == 0) store_empty_tile(a, v, tx * GGS_TILE, ty * GGS_TILE, lane);
+            return;
+        }
+    }
     const bool inside = px < a.W && py < a.H;
     float pxf = inside ? (float)px : inf_v;
     const float pyf = (float)py;
