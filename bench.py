@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--n-rows", type=int, default=250)
     ap.add_argument("--cpu-views", type=int, default=40, help="views of the workload timed on the CPU oracle (0 = skip)")
     ap.add_argument("--loop-views", type=int, default=16, help="views timed through the per-view drop-in render() loop")
+    ap.add_argument("--extra-configs", type=int, default=1,
+                    help="1: also time the K = 16 variant of config 2 and the stress config 5 (N = 1 only; 0 = skip)")
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every step eagerly instead of replaying the captured hipGraph of its compute part")
@@ -66,6 +68,65 @@ def alg_bytes(P, K, P_vis, N, HW, T):
         "render_bwd": HW * 20 + N * 44 + P_vis * 36,
         "preprocess_bwd": P * (44 + 12 * K) + P_vis * 84 + P * (56 + 12 * K),
     }
+
+
+def extra_config(name, dev, *, sh_degree, n_around, n_rows, W, H, views, chunk, steps):
+    """One more workload of the same hot path, timed the same way (fwd+bwd of `views` views per step through the batched
+    entry points, eager launches) and priced against the same roofline: the K = 16 variant of config 2 and the stress
+    config 5 of BASELINE.json.  Returns the extra keys of the JSON line."""
+    import ctypes as C
+    from ggsplat import _lib, batch, rasterizer as R, synthetic as S
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    K = (sh_degree + 1) ** 2
+    verts, faces = S.skirt_mesh(n_around, n_rows)
+    Fn = faces.shape[0]
+    model = MeshGaussianModel.from_tensors(verts, faces, S.skirt_gaussian_params(Fn, sh_degree=sh_degree), sh_degree=sh_degree, device=dev)
+    f = 1500.0 * W / 1920.0
+    cams = S.stack_cameras(S.rig_cameras(n_rings=max(1, views // 32), n_az=min(32, views), width=W, height=H, f=f)[:views], device=dev)
+    bg = torch.zeros(3, device=dev)
+    dL = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1234)).to(dev).unsqueeze(0).expand(chunk, 3, H, W).contiguous()
+    model.update_face_coor()
+    with torch.no_grad():
+        inputs = dict(means3D=model.get_xyz.detach(), scales=model.get_scaling.detach(), rotations=model.get_rotation.detach(),
+                      opacities=model.get_opacity.detach(), shs=model.get_features.detach())
+
+    def step():
+        return batch.fwd_bwd_views(inputs, cams, bg=bg, W=W, H=H, sh_degree=sh_degree, chunk=chunk,
+                                   dL_dcolor_fn=lambda v0, v1, color: dL[:v1 - v0])
+    gr = step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gr = step()
+    torch.cuda.synchronize(dev)
+    vps = views * steps / (time.perf_counter() - t0)
+    L = _lib.lib()
+    L.ggs_profile_enable(1)
+    cs = {k: v[:chunk] for k, v in cams.items()}
+    color, radii, depth, alpha, st = R.forward_views(
+        inputs["means3D"], inputs["opacities"], inputs["shs"], None, inputs["scales"], inputs["rotations"], None,
+        view=cs["view"], proj=cs["proj"], campos=cs["campos"], tanfov=cs["tanfov"], bg=bg, W=W, H=H, sh_degree=sh_degree)
+    buf = (C.c_float * 8)()
+    L.ggs_profile_read(buf, 8)
+    fwd_ms = list(buf)[:5]
+    R.backward_views(st, dL[:chunk], want_means2D=False)
+    L.ggs_profile_read(buf, 8)
+    L.ggs_profile_enable(0)
+    ms = dict(zip(KERNELS, fwd_ms + list(buf)[5:7] + [buf[7]]))
+    N_view = st.num_rendered / chunk
+    P_vis = float((radii > 0).sum().item()) / chunk
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    B = alg_bytes(Fn, K, P_vis, N_view, W * H, T)
+    dom = max(("render_fwd", "render_bwd", "preprocess", "preprocess_bwd"), key=lambda k: ms[k])
+    dom_gbs = B[dom] * chunk / (ms[dom] * 1e-3) / 1e9
+    B_view = sum(B.values())
+    return {"workload": f"{name}: {Fn} mesh-bound Gaussians, {W}x{H}, SH degree {sh_degree}, {views} views per step, "
+                        f"{chunk} per launch, eager launches", "value": round(vps, 2), "unit": "views/s",
+            "num_rendered_per_view": round(N_view, 1),
+            "roofline": {"kernel": "ggs_k_" + dom, "achieved": round(dom_gbs, 2), "frac": round(dom_gbs / HBM_PEAK_GBS, 5),
+                         "kernel_ms_per_launch": {k: round(v, 4) for k, v in ms.items()},
+                         "whole_path": {"alg_bytes_per_view": int(B_view), "achieved_GBs": round(B_view * vps / 1e9, 2),
+                                        "frac": round(B_view * vps / 1e9 / HBM_PEAK_GBS, 5)}}}
 
 
 def spawn_ranks(args):
@@ -114,7 +175,8 @@ def main():
     Fn = faces.shape[0]
     params = S.skirt_gaussian_params(Fn, sh_degree=args.sh_degree)
     model = MeshGaussianModel.from_tensors(verts, faces, params, sh_degree=args.sh_degree, device=dev)
-    all_cams = S.rig_cameras(n_rings=max(1, args.views // 32), n_az=min(32, args.views), width=W, height=H)[:args.views]
+    all_cams = S.rig_cameras(n_rings=max(1, args.views // 32), n_az=min(32, args.views), width=W, height=H,
+                             f=1500.0 * W / 1920.0)[:args.views]          # same field of view at every resolution
     n_views_total = len(all_cams) if args.scaling == "strong" else len(all_cams) * world
     my = shard_views(len(all_cams), rank, world) if args.scaling == "strong" else list(range(len(all_cams)))
     cams = S.stack_cameras([all_cams[i] for i in my], device=dev)
@@ -409,6 +471,16 @@ def main():
                               "sample": "BASELINE configs[0] in full: 10k Gaussians, SH degree 3, 4 cameras 512x512, fwd+bwd, "
                                         "median of 3 passes"}
 
+        extras = None
+        if args.extra_configs and world == 1 and (W, H, Fn, args.sh_degree) == (1920, 1080, 100000, 0):
+            torch.cuda.empty_cache()
+            extras = {"config2_sh3": extra_config("config 2 with SH degree 3 (the s3 setting)", dev, sh_degree=3, n_around=200,
+                                                   n_rows=250, W=1920, H=1080, views=64, chunk=32, steps=4)}
+            torch.cuda.empty_cache()
+            extras["config5_stress"] = extra_config("config 5 (stress)", dev, sh_degree=3, n_around=500, n_rows=500, W=3840,
+                                                    H=2160, views=32, chunk=16, steps=3)
+            torch.cuda.empty_cache()
+
         out = {
             "metric": "fwd+bwd views/sec @1080p, 100k mesh-Gaussians",
             "value": round(views_per_sec, 2), "unit": "views/s", "n_gpus": world, "steps": args.steps,
@@ -423,7 +495,7 @@ def main():
                        "mean_list_length_per_pixel": round(N_view / T, 2),
                        "mean_last_contributor_per_pixel": round(mean_contrib, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
-            "build_id": bid, "library_matches_sources": bid == _lib.source_hash(),
+            "build_id": bid, "library_matches_sources": bid == _lib.source_hash(), "other_configs": extras,
             "per_view_loop_views_per_sec": None if loop_vps is None else round(loop_vps, 2),
             "s2_inner_step_iters_per_sec": None if step_vps is None else round(step_vps, 2),
             "s2_graph_step_iters_per_sec": None if graph_vps is None else round(graph_vps, 2),
