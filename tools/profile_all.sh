@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/$TAG
 mkdir -p $R/gpurun_out
-BENCH="python $R/bench.py --cpu-views 0 --loop-views 0 $*"
+BENCH="python $R/bench.py --cpu-views 0 --loop-views 0 --extra-configs 0 $*"
 python -c "import sys; sys.path.insert(0, '$R/gaussian-garments_amd'); from ggsplat import _lib; print(_lib.build_id())" > ${OUT}_build_id.txt
 echo "$*" > ${OUT}_args.txt
 timeout 600 rocprofv3 --kernel-trace --stats -d ${OUT}_trace -o t -- $BENCH --steps 3 --warmup 1 > ${OUT}_trace.log 2>&1 || echo "trace pass failed" >> ${OUT}_trace.log

@@ -60,13 +60,13 @@ def main(tag, prefix, workload):
             sys.stdout = f
             rocpd_summary.main(t)
             sys.stdout = old
-            f.write(f"\nSource: `rocprofv3 --kernel-trace --stats -- python bench.py --cpu-views 0 --loop-views 0 {bargs} --steps 3 "
+            f.write(f"\nSource: `rocprofv3 --kernel-trace --stats -- python bench.py --cpu-views 0 --loop-views 0 --extra-configs 0 {bargs} --steps 3 "
                     f"--warmup 1` on one MI355X, library build {bid}.\n")
     s = db(tag, "sq")
     if s:
         sq_table(s, prefix + "_sq_counters.md",
                  f"# SQ counters (rocprofv3 --pmc, one pass, kernel-trace only), build {bid}\n\n`python bench.py --cpu-views 0 "
-                 f"--loop-views 0 {bargs} --steps 1 --warmup 0 --views 32`; wave-cycle counters are in quad-cycles.\n\n")
+                 f"--loop-views 0 --extra-configs 0 {bargs} --steps 1 --warmup 0 --views 32`; wave-cycle counters are in quad-cycles.\n\n")
     fe, wr = db(tag, "fetch"), db(tag, "write")
     if fe and wr:
         hbm_summary.main(fe, wr, prefix + "_hbm_traffic", int(os.environ.get("PMC_VIEWS", "32")), bid, workload)
