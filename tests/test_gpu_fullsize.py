@@ -129,6 +129,28 @@ def test_batch_equals_single_views_bitwise(scene):
         assert torch.equal(d1[0], depth[v]) and torch.equal(a1[0], alpha[v])
 
 
+def test_latency_mapping_equals_throughput_mapping_bitwise(scene):
+    """A launch of 8 views runs one wave per tile (4 pixels per lane), a launch of one view one wave per (tile, quadrant)
+    with several list entries in flight and the transmittance advanced optimistically: same arithmetic per pixel, so the
+    images, final_T and the last-contributor positions must be identical bit for bit; the gradients agree to the order of
+    their float atomics."""
+    from ggsplat import rasterizer as R
+    inp, ck = scene
+    P = inp["means3D"].shape[0]
+    col = torch.rand(P, 3, generator=torch.Generator().manual_seed(6)).cuda()
+    rep = {k: v[2:3].expand(8, *v.shape[1:]).contiguous() for k, v in ck.items()}        # the same camera 8 times
+    c8, r8, d8, a8, st8 = _fwd(inp, rep, colors=col, bg=(0.1, 0.2, 0.3), keep=True)
+    c1, r1, d1, a1, st1 = _fwd(inp, ck, colors=col, bg=(0.1, 0.2, 0.3), keep=True, views=slice(2, 3))
+    assert torch.equal(c1[0], c8[5]) and torch.equal(d1[0], d8[5]) and torch.equal(a1[0], a8[5]) and torch.equal(r1[0], r8[5])
+    s1, s8 = R.img_sections(st1), R.img_sections(st8)
+    assert torch.equal(s1["final_T"][0], s8["final_T"][5]) and torch.equal(s1["n_contrib"][0], s8["n_contrib"][5])
+    w = torch.randn(1, 3, H, W, generator=torch.Generator().manual_seed(7)).cuda()
+    g1 = R.backward_views(st1, w, want_means2D=False)
+    g8 = R.backward_views(st8, w.expand(8, 3, H, W).contiguous(), want_means2D=False)
+    for k in ("means3D", "opacities", "colors_precomp", "scales", "rotations"):
+        assert float((g1[k] * 8 - g8[k]).abs().sum() / g8[k].abs().sum()) < 1e-5, k
+
+
 def test_one_view_against_the_c_oracle(scene):
     """The C oracle (OpenMP, all host cores) does finish ONE 1080p view of config 2 in well under a second on the GPU
     box's host: image, depth, alpha, radii and every gradient of that view against the HIP path, at the north-star
