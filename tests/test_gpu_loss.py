@@ -86,6 +86,7 @@ def test_fused_loss_batched_views_and_1080p_speed():
     def torch_ops():
         z = img[0].clone().requires_grad_(True)
         (l1_loss(z, gt[0], mask[0]) * 0.8 + 1.0 - ssim(z + 0, gt[0].clone(), mask[0]) * 0.2).backward()
-    tf, tt = timed(fused), timed(torch_ops)
+    # best of three trials each: a single host hiccup (the box also runs the profiler's daemons) must not fail a parity suite
+    tf, tt = min(timed(fused) for _ in range(3)), min(timed(torch_ops) for _ in range(3))
     print(f"\\nphotometric loss fwd+bwd @1080p: fused {tf*1e3:.3f} ms, PyTorch ops {tt*1e3:.3f} ms ({tt/tf:.1f}x)")
     assert tf < tt
