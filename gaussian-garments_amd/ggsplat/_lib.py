@@ -101,7 +101,7 @@ def ptr(t):
 
 _SRC_ORDER = ("ggs_pergauss.hip", "ggs_binning.hip", "ggs_render.hip", "ggs_render_seg.hip", "ggs_mesh.hip", "ggs_loss.hip", "ggs_knn.hip",
               "ggs_stylegan.hip", "ggs_visibility.hip", "ggs_adam.hip", "ggs_regaux.hip", "ggs_api.hip", "ggs_common.h",
-              "ggs_kernels.h", "ggs_render_common.h", os.path.join("..", "..", "include", "ggsplat.h"))
+              "ggs_kernels.h", "ggs_render_common.h", os.path.join("..", "..", "include", "ggsplat.h"), "Makefile")
 
 
 def source_hash() -> str:
