@@ -354,11 +354,24 @@ def main():
                     break
             except Exception:
                 continue
+        # VALU occupancy of the same kernel from the committed PMC collection of this build (tools/profile_all.sh, pass "valu"):
+        # the render kernels are bound by VALU issue, not by the HBM pipe the contract prices them against
+        valu = None
+        for fn in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_valu.json")), reverse=True):
+            try:
+                vj = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                if vj.get("build_id") == bid and vj.get("workload") == {"P": Fn, "W": W, "H": H, "sh_degree": args.sh_degree}:
+                    kv = vj["kernels"]["ggs_k_" + dom + ("_sh%d" % args.sh_degree if dom == "preprocess_bwd" else "")]
+                    valu = {"busy_pct": kv.get("rocprof_valu_busy_pct") or kv["valu_busy_pct"],
+                            "lane_activity_pct": kv.get("rocprof_lane_activity_pct") or kv["lane_activity_pct"], "source": "profiles/" + fn}
+                    break
+            except Exception:
+                continue
         roofline = {"bound": "hbm", "kernel": "ggs_k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_src if traffic is not None else
                     f"none: no profiles/*_hbm_traffic.json was collected from build {bid} on this workload",
-                    "launch_views": chunk, "launch_ms": round(group_ms[dom], 4),
+                    "valu": valu, "launch_views": chunk, "launch_ms": round(group_ms[dom], 4),
                     "alg_bytes_per_launch": int(dom_bytes),
                     "kernel_ms_per_launch": {k: round(v, 4) for k, v in kern_ms.items()},
                     # B_ref: the same lower bound with the reference algorithm's global radix sort of 64-bit

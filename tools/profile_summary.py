@@ -49,6 +49,47 @@ def sq_table(path, out, header):
                     f"{g('SQ_ACTIVE_INST_VALU') / max(g('SQ_INSTS_VALU'), 1):.2f} | {dur.get(k, 0):.0f} |\n")
 
 
+def valu_table(path, prefix, bid, bargs, workload, derived_path=None):
+    """VALUBusy = 100 sum(SQ_ACTIVE_INST_VALU) / CU_NUM / max(GRBM_GUI_ACTIVE) and VALUUtilization = 100 sum(SQ_THREAD_CYCLES_VALU)
+    / (sum(SQ_ACTIVE_INST_VALU) 64) -- rocprofiler-sdk's own gfx950 formulas (counter_defs.yaml), evaluated per kernel."""
+    cur = sqlite3.connect(path).cursor()
+    rows = {}
+    for name, counter, n, total, mx in cur.execute(
+            "select kernel_name, counter_name, count(*), sum(value), max(value) from counters_collection group by kernel_name, counter_name"):
+        m = re.match(r"(ggs_k_\w+)", name)
+        if m:
+            rows.setdefault(m.group(1), {})[counter] = (n, total, mx)
+    CU, XCD = 256, 8                      # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs; the formula wants the max = sum / 8
+    derived = {}
+    if derived_path:                      # rocprofv3 evaluating its own derived metrics (per dispatch; averaged here)
+        for name, counter, avg in sqlite3.connect(derived_path).cursor().execute(
+                "select kernel_name, counter_name, avg(value) from counters_collection group by kernel_name, counter_name"):
+            m = re.match(r"(ggs_k_\w+)", name)
+            if m:
+                derived.setdefault(m.group(1), {})[counter] = avg
+    out = {"build_id": bid, "workload": workload, "bench_args": bargs, "views_per_launch": int(os.environ.get("PMC_VIEWS", "32")), "kernels": {}}
+    with open(prefix + "_valu.md", "w") as f:
+        f.write(f"# VALU occupancy and lane activity (rocprofv3 --pmc, own pass), build {bid}\n\n`python bench.py --cpu-views 0 --loop-views 0 "
+                f"--extra-configs 0 {bargs} --steps 1 --warmup 0 --views {out['views_per_launch']}`.  VALUBusy and VALUUtilization are "
+                "rocprofiler-sdk's gfx950 formulas; GRBM_GUI_ACTIVE is taken per XCD (the counter arrives summed over the 8) and summed over the launches of a kernel.\n\n| kernel | launches | VALU insts / launch | GRBM_GUI_ACTIVE cycles / launch | VALUBusy % | active lanes per VALU "
+                "instruction (VALUUtilization %) | SQ_BUSY_CYCLES / launch | rocprofv3 VALUBusy | rocprofv3 VALUUtilization |\n|---|---|---|---|---|---|---|---|---|\n")
+        for k, c in sorted(rows.items()):
+            g = lambda n: c.get(n, (1, 0.0, 0.0))[1]
+            n = c["SQ_INSTS_VALU"][0]
+            gui = max(g("GRBM_GUI_ACTIVE") / XCD, 1.0)
+            act = max(g("SQ_ACTIVE_INST_VALU"), 1.0)
+            busy = 100.0 * act / CU / gui
+            util = 100.0 * g("SQ_THREAD_CYCLES_VALU") / (act * 64.0)
+            out["kernels"][k] = {"valu_busy_pct": round(busy, 2), "lane_activity_pct": round(util, 2), "valu_insts_per_launch": g("SQ_INSTS_VALU") / n,
+                                 "gui_active_cycles_per_launch": gui / n}
+            dv = derived.get(k, {})
+            if dv:
+                out["kernels"][k].update(rocprof_valu_busy_pct=dv.get("VALUBusy"), rocprof_lane_activity_pct=dv.get("VALUUtilization"))
+            f.write(f"| {k} | {n} | {g('SQ_INSTS_VALU') / n:.3e} | {gui / n:.3e} | {busy:.1f} | {util:.1f} | {g('SQ_BUSY_CYCLES') / n:.3e} | "
+                    f"{dv.get('VALUBusy', float('nan')):.1f} | {dv.get('VALUUtilization', float('nan')):.1f} |\n")
+    json.dump(out, open(prefix + "_valu.json", "w"), indent=1)
+
+
 def main(tag, prefix, workload):
     g = os.path.join(ROOT, "gpurun_out")
     bid = open(os.path.join(g, f"{tag}_build_id.txt")).read().strip()
@@ -67,6 +108,9 @@ def main(tag, prefix, workload):
         sq_table(s, prefix + "_sq_counters.md",
                  f"# SQ counters (rocprofv3 --pmc, one pass, kernel-trace only), build {bid}\n\n`python bench.py --cpu-views 0 "
                  f"--loop-views 0 --extra-configs 0 {bargs} --steps 1 --warmup 0 --views 32`; wave-cycle counters are in quad-cycles.\n\n")
+    u = db(tag, "valu")
+    if u:
+        valu_table(u, prefix, bid, bargs, workload, db(tag, "valud"))
     fe, wr = db(tag, "fetch"), db(tag, "write")
     if fe and wr:
         hbm_summary.main(fe, wr, prefix + "_hbm_traffic", int(os.environ.get("PMC_VIEWS", "32")), bid, workload)
