@@ -7,22 +7,21 @@
 //     loss_ssim = 1 - mean(ssim_map(img * mask, gt * mask)) * lambda
 // which costs 5 grouped conv2d forward + their backward (~10x the image bytes, milliseconds at 1080p --
 // several times the HIP rasterizer's forward+backward).  Here:
-//   pass A (ggs_k_loss_stats): per 32x32 tile and channel, x = img*mask and y = gt*mask (+5 px halo, zero
-//           padded like conv2d(padding=5)) go to LDS; separable 11-tap window (same fp32 taps as
-//           create_window) gives mu1, mu2, E[xx], E[yy], E[xy]; the SSIM map value and its three partial
-//           derivatives (d/dmu1 total, d/dE[xx], d/dE[xy]) are formed per pixel; block-reduced sums of
-//           |x - y| and of the map go to sums[v] (one atomic pair per block).
+//   pass A (ggs_k_loss_stats): x = img*mask and y = gt*mask (zero padded like conv2d(padding=5)); separable 11-tap
+//           window (same fp32 taps as create_window) gives mu1, mu2, E[xx], E[yy], E[xy]; the SSIM map value and
+//           its three partial derivatives (d/dmu1 total, d/dE[xx], d/dE[xy]) are formed per pixel; workgroup-reduced
+//           sums of |x - y| and of the map go to sums[v] (one atomic pair per workgroup).
 //   pass B (ggs_k_loss_grad): the three derivative maps are filtered with the same (symmetric) window:
 //           dSSIM/dx = G*dmu1 + 2 x (G*dExx) + y (G*dExy); combined with the L1 sign term and the mask.
-// Roofline: HBM (A: reads 24 B/px(+mask) writes 36 B/px; B: reads 60 B/px writes 12 B/px ~ 270 MB per 1080p
-// view); ~530 MAC per pixel, far below the fp32 peak, so LDS traffic of the separable passes is what is tuned.
+// Both passes stream rows through one wave per 64-column strip (see below): the horizontal filter reads a wave-private
+// LDS row, the vertical filter is a ring of partial sums in registers.
+// Roofline: HBM for the batched call (A: reads 24 B/px(+mask) writes 36 B/px; B: reads 60 B/px writes 12 B/px ~ 270 MB
+// per 1080p view; B moves ~4.8 TB/s at 32 views), VALU for pass A (~215 instructions per pixel row and lane).
 #include "ggs_kernels.h"
 
 namespace {
 
-#define LT 32                 // output tile edge
 #define LH 5                  // window half width
-#define LI (LT + 2 * LH)      // input tile edge incl. halo = 42
 #define SSIM_C1 0.0001f       // 0.01^2
 #define SSIM_C2 0.0009f       // 0.03^2
 
@@ -52,218 +51,294 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
     return v;
 }
 
-}  // namespace
+// ---- row streaming ------------------------------------------------------------------------------------------------
+// One wave64 = one strip of 64 output columns x LS_HB output rows of one (view, channel); the wave walks its
+// LS_HB + 10 input rows top to bottom.  Per input row: the 74 masked x / y values go through a wave-private LDS row
+// (double buffered; one wave = no barrier), every lane filters its column horizontally (11 taps, 5 maps), and the
+// vertical filter is a REGISTER ring: the row's five horizontal sums are added, with tap k, to the partial sums of the 11
+// output rows they belong to; the output row that received its last tap is finished (SSIM value + derivative maps).
+// Taps are accumulated in the order 0..10 in both directions.  Against round 1's 32x32 LDS tiles (five intermediate maps
+// = 27 KB per tile, 3 workgroups per CU, three barriers per channel) there are no workgroup barriers, no LDS round trip of
+// the intermediate maps and ~1 KB of LDS per wave: occupancy is set by the registers alone (pass A: 128 VGPRs, 4 waves per
+// SIMD; 32 views 1.84 -> 1.54 ms and 1.61 -> 1.40 ms, one view 76 -> 56 us and 56 -> 42 us).  The ring index is static because the row loop is unrolled by 11.
+// Memory pipeline of a step: park the row loaded during the previous step -> write the previous step's outputs -> start
+// the loads of the next row -> filter.  Loads are branch-free (clamped addresses, padding applied at park time) and the
+// stores are issued BEFORE the loads that the next step waits for: vmcnt retires in order, so a store issued after
+// them would put its whole write latency on the critical path of every step.
+#define LS_COLS 64
+#define LS_HB 34                          // LS_HB + 2 LH = 44 input rows = 4 x 11
+#define LS_IN (LS_COLS + 2 * LH)          // 74
+#define LS_WAVES 4                        // waves per workgroup: consecutive bands of one strip
 
-// Pass A: grid (ceil(W/32), ceil(H/32), V), block 256.  A workgroup walks the three colour channels of its tile: the
-// mask and the index arithmetic are shared, and the global loads of channel c + 1 are in flight while channel c is
-// filtered (with 3 workgroups per CU -- LDS -- nothing else hides the HBM latency of the tile + halo reads).
-__global__ __launch_bounds__(256) void ggs_k_loss_stats(LossArgs a) {
-    __shared__ float sx[LI][LI + 1], sy[LI][LI + 1];
-    __shared__ float hh[5][LI][LT + 1];
-    __shared__ float s_red[4];
-    const int tid = threadIdx.x;
-    const int v = blockIdx.z;
-    const int ox = blockIdx.x * LT, oy = blockIdx.y * LT;
+template <int NM>
+struct RowRing { float v[11][NM]; };
+
+// tap k of input row (ring phase R) lands in slot (R - k) mod 11; k = 0 starts the sum of a new output row
+template <int NM, int R>
+__device__ __forceinline__ void ring_add(RowRing<NM>& ring, const float (&h)[NM]) {
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const int slot = (R - k + 11) % 11;
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+            ring.v[slot][m] = k == 0 ? G11[0] * h[m] : fmaf(G11[k], h[m], ring.v[slot][m]);
+    }
+}
+
+// addresses of the two input columns of a lane in input row y, clamped into the image (ok = not padding)
+struct RowAddr { size_t p1, p2; bool ok1, ok2; };
+__device__ __forceinline__ RowAddr row_addr(int y, int H, int W, int ox, int lane) {
+    const int c1 = ox - LH + lane, c2 = ox + LS_COLS - LH + lane;
+    const bool has2 = lane < 2 * LH;
+    const bool oky = y >= 0 && y < H;
+    RowAddr r;
+    r.ok1 = oky && c1 >= 0 && c1 < W;
+    r.ok2 = oky && has2 && c2 < W;
+    const size_t row = (size_t)min(max(y, 0), H - 1) * W;
+    r.p1 = row + min(max(c1, 0), W - 1);
+    r.p2 = row + min(max(has2 ? c2 : c1, 0), W - 1);
+    return r;
+}
+
+struct StatsRow { float x1, y1, m1, x2, y2, m2; bool ok1, ok2; };       // raw values of the next input row
+template <bool MASK>
+__device__ __forceinline__ StatsRow stats_load_row(const float* __restrict__ img, const float* __restrict__ gt,
+                                                  const float* __restrict__ mask, int y, int H, int W, int ox, int lane) {
+    const RowAddr ad = row_addr(y, H, W, ox, lane);
+    StatsRow r;
+    r.ok1 = ad.ok1; r.ok2 = ad.ok2;
+    r.x1 = img[ad.p1]; r.y1 = gt[ad.p1]; r.m1 = MASK ? mask[ad.p1] : 1.f;
+    r.x2 = img[ad.p2]; r.y2 = gt[ad.p2]; r.m2 = MASK ? mask[ad.p2] : 1.f;
+    return r;
+}
+
+struct StatsCtx {
+    const float *img, *gt, *mask;
+    float* dm;
+    int H, W, oy, ox, lane;
+    size_t HW;
+    float (*sx)[LS_IN];       // [2][LS_IN] wave-private
+    float (*sy)[LS_IN];
+    float l1, ssum;
+    StatsRow nxt;
+    float o0, o1, o2;         // outputs of the previous step, written at the start of this one
+    bool pend;
+};
+
+template <int R, bool MASK>
+__device__ __forceinline__ void stats_step(StatsCtx& c, RowRing<5>& ring, int i) {
+    const int buf = i & 1;
+    const int lane = c.lane;
+    const int x = c.ox + lane;
+    c.sx[buf][lane] = c.nxt.ok1 ? c.nxt.x1 * c.nxt.m1 : 0.f; c.sy[buf][lane] = c.nxt.ok1 ? c.nxt.y1 * c.nxt.m1 : 0.f;
+    if (lane < 2 * LH) {
+        c.sx[buf][LS_COLS + lane] = c.nxt.ok2 ? c.nxt.x2 * c.nxt.m2 : 0.f;
+        c.sy[buf][LS_COLS + lane] = c.nxt.ok2 ? c.nxt.y2 * c.nxt.m2 : 0.f;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (c.pend) {                                                        // output row i - 1 - 2 LH
+        const size_t p = (size_t)(c.oy + i - 1 - 2 * LH) * c.W + x;
+        c.dm[p] = c.o0; c.dm[c.HW + p] = c.o1; c.dm[2 * c.HW + p] = c.o2;
+    }
+    c.nxt = stats_load_row<MASK>(c.img, c.gt, c.mask, c.oy - LH + i + 1, c.H, c.W, c.ox, lane);
+    float xs[11], ys[11];
+#pragma unroll
+    for (int k = 0; k < 11; ++k) { xs[k] = c.sx[buf][lane + k]; ys[k] = c.sy[buf][lane + k]; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float h[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 11; ++k) {
+        const float g = G11[k], xv = xs[k], yv = ys[k];
+        h[0] = fmaf(g, xv, h[0]); h[1] = fmaf(g, yv, h[1]);
+        h[2] = fmaf(g, xv * xv, h[2]); h[3] = fmaf(g, yv * yv, h[3]); h[4] = fmaf(g, xv * yv, h[4]);
+    }
+    // L1 over the strip's own pixels (the row is an own row when LH <= i < LH + LS_HB)
+    if (i >= LH && i < LH + LS_HB && c.oy + i - LH < c.H && x < c.W) c.l1 += fabsf(xs[LH] - ys[LH]);
+    ring_add<5, R>(ring, h);
+    const int o = i - 2 * LH;                       // the output row that just received tap 10
+    c.pend = o >= 0 && c.oy + o < c.H && x < c.W;
+    {
+        constexpr int slot = (R + 1) % 11;
+        const float m1 = ring.v[slot][0], m2 = ring.v[slot][1], e11 = ring.v[slot][2], e22 = ring.v[slot][3],
+                    e12 = ring.v[slot][4];
+        const float v1 = e11 - m1 * m1, v2 = e22 - m2 * m2, cv = e12 - m1 * m2;
+        const float A1 = 2.f * m1 * m2 + SSIM_C1, A2 = 2.f * cv + SSIM_C2;
+        const float B1 = m1 * m1 + m2 * m2 + SSIM_C1, B2 = v1 + v2 + SSIM_C2;
+        const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
+        const float inv = iB1 * iB2;
+        const float S = A1 * A2 * inv;
+        if (c.pend) c.ssum += S;
+        c.o0 = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * iB1 + 2.f * m1 * S * iB2;
+        c.o1 = -S * iB2;
+        c.o2 = 2.f * A1 * inv;
+    }
+}
+
+template <int R, typename Step, typename Ctx, typename Ring>
+__device__ __forceinline__ void unroll11(Ctx& c, Ring& ring, int i0) {
+    if constexpr (R < 11) {
+        Step::template run<R>(c, ring, i0 + R);
+        unroll11<R + 1, Step>(c, ring, i0);
+    }
+}
+template <bool MASK>
+struct StatsStep {
+    template <int R> static __device__ __forceinline__ void run(StatsCtx& c, RowRing<5>& r, int i) { stats_step<R, MASK>(c, r, i); }
+};
+
+template <bool MASK>
+__device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float (*s_x)[2][LS_IN], float (*s_y)[2][LS_IN],
+                                                       float* s_red) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int v = blockIdx.z / 3, ch = blockIdx.z % 3;
+    const int band = blockIdx.y * LS_WAVES + wave;
     const size_t HW = (size_t)a.H * a.W;
-    const float* mask = a.mask ? a.mask + (size_t)v * HW : nullptr;
-
-    constexpr int NL = (LI * LI + 255) / 256;
-    float xr[NL], yr[NL], mr[NL];
-    size_t pp[NL];
-    bool in[NL];
-    {
-        const float* img = a.img + (size_t)v * 3 * HW;
-        const float* gt = a.gt + (size_t)v * 3 * HW;
+    StatsCtx c;
+    c.img = a.img + ((size_t)v * 3 + ch) * HW; c.gt = a.gt + ((size_t)v * 3 + ch) * HW;
+    c.mask = MASK ? a.mask + (size_t)v * HW : nullptr;
+    c.dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW;
+    c.H = a.H; c.W = a.W; c.oy = band * LS_HB; c.ox = blockIdx.x * LS_COLS; c.lane = lane; c.HW = HW;
+    c.sx = s_x[wave]; c.sy = s_y[wave];
+    c.l1 = 0.f; c.ssum = 0.f; c.pend = false; c.o0 = c.o1 = c.o2 = 0.f;
+    if (c.oy < a.H) {
+        RowRing<5> ring;
 #pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int i = tid + j * 256;
-            const int r = i / LI, c = i % LI;
-            const int y = oy + r - LH, x = ox + c - LH;
-            in[j] = i < LI * LI && x >= 0 && x < a.W && y >= 0 && y < a.H;
-            pp[j] = in[j] ? (size_t)y * a.W + x : 0;
-            xr[j] = in[j] ? img[pp[j]] : 0.f;
-            yr[j] = in[j] ? gt[pp[j]] : 0.f;
-            mr[j] = (in[j] && mask) ? mask[pp[j]] : 1.f;
+        for (int j = 0; j < 11; ++j)
+#pragma unroll
+            for (int m = 0; m < 5; ++m) ring.v[j][m] = 0.f;
+        c.nxt = stats_load_row<MASK>(c.img, c.gt, c.mask, c.oy - LH, c.H, c.W, c.ox, lane);
+        for (int i0 = 0; i0 < LS_HB + 2 * LH; i0 += 11) unroll11<0, StatsStep<MASK>>(c, ring, i0);
+        if (c.pend) {                                                    // the last output row
+            const size_t p = (size_t)(c.oy + LS_HB - 1) * c.W + c.ox + lane;
+            c.dm[p] = c.o0; c.dm[HW + p] = c.o1; c.dm[2 * HW + p] = c.o2;
         }
     }
-    float l1 = 0.f, ssum = 0.f;
-    for (int ch = 0; ch < 3; ++ch) {
-    {
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int i = tid + j * 256;
-            if (i >= LI * LI) continue;
-            const int r = i / LI, c = i % LI;
-            const float xv = xr[j] * mr[j], yv = yr[j] * mr[j];
-            // the L1 term is summed over the tile's own pixels only (not the halo)
-            if (in[j] && r >= LH && r < LH + LT && c >= LH && c < LH + LT) l1 += fabsf(xv - yv);
-            sx[r][c] = xv; sy[r][c] = yv;
-        }
-    }
-    __syncthreads();
-    if (ch < 2) {                      // next channel's tile + halo: consumed after this channel's two filter passes
-        const float* img = a.img + ((size_t)v * 3 + ch + 1) * HW;
-        const float* gt = a.gt + ((size_t)v * 3 + ch + 1) * HW;
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            xr[j] = in[j] ? img[pp[j]] : 0.f;
-            yr[j] = in[j] ? gt[pp[j]] : 0.f;
-        }
-    }
-    // horizontal pass, register blocked: thread = (row, 8 adjacent output columns) reads its 18 inputs of x and y once
-    // (36 LDS reads for 8 outputs x 5 maps instead of 176) -- the kernel is bound by LDS latency, not by the FMAs.
-    // Accumulation order per output is unchanged (taps 0..10).
-    {
-        const int r = tid >> 2, c0 = (tid & 3) * 8;
-        if (r < LI) {
-            float xv[18], yv[18];
-#pragma unroll
-            for (int j = 0; j < 18; ++j) { xv[j] = sx[r][c0 + j]; yv[j] = sy[r][c0 + j]; }
-#pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 11; ++k) {
-                    const float g = G11[k], x = xv[o + k], y = yv[o + k];
-                    m1 = fmaf(g, x, m1); m2 = fmaf(g, y, m2);
-                    e11 = fmaf(g, x * x, e11); e22 = fmaf(g, y * y, e22); e12 = fmaf(g, x * y, e12);
-                }
-                hh[0][r][c0 + o] = m1; hh[1][r][c0 + o] = m2; hh[2][r][c0 + o] = e11; hh[3][r][c0 + o] = e22;
-                hh[4][r][c0 + o] = e12;
-            }
-        }
-    }
-    __syncthreads();
-    // vertical pass + SSIM map + derivative maps: thread = (column, 4 adjacent output rows), 14 reads per map
-    float* dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW;
-    {
-        const int c = tid & 31, r0 = (tid >> 5) * 4;
-        const int x = ox + c;
-        float col[5][14];
-#pragma unroll
-        for (int m = 0; m < 5; ++m)
-#pragma unroll
-            for (int j = 0; j < 14; ++j) col[m][j] = hh[m][r0 + j][c];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const int y = oy + r0 + o;
-            if (x >= a.W || y >= a.H) continue;
-            float m1 = 0.f, m2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float g = G11[k];
-                m1 = fmaf(g, col[0][o + k], m1); m2 = fmaf(g, col[1][o + k], m2);
-                e11 = fmaf(g, col[2][o + k], e11); e22 = fmaf(g, col[3][o + k], e22);
-                e12 = fmaf(g, col[4][o + k], e12);
-            }
-            const float v1 = e11 - m1 * m1, v2 = e22 - m2 * m2, cv = e12 - m1 * m2;
-            const float A1 = 2.f * m1 * m2 + SSIM_C1, A2 = 2.f * cv + SSIM_C2;
-            const float B1 = m1 * m1 + m2 * m2 + SSIM_C1, B2 = v1 + v2 + SSIM_C2;
-            // two v_rcp_f32 (1 ulp) instead of five IEEE divisions (~10 instructions each); B1, B2 >= C1, C2 > 0
-            const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
-            const float inv = iB1 * iB2;
-            const float S = A1 * A2 * inv;
-            ssum += S;
-            const size_t p = (size_t)y * a.W + x;
-            // total derivative w.r.t. mu1 (through A1, A2 = 2(E12 - m1 m2) + C2, B1, B2 = E11 - m1^2 + ...)
-            dm[p] = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * iB1 + 2.f * m1 * S * iB2;
-            dm[HW + p] = -S * iB2;                // d/dE[xx]
-            dm[2 * HW + p] = 2.f * A1 * inv;      // d/dE[xy]
-        }
-    }
-    __syncthreads();                   // hh and sx / sy are rewritten by the next channel
-    }  // ch
-    l1 = block_sum(l1, s_red);
-    ssum = block_sum(ssum, s_red);
-    if (tid == 0) {
+    const float l1 = block_sum(c.l1, s_red), ssum = block_sum(c.ssum, s_red);
+    if (threadIdx.x == 0) {
         atomicAdd(&a.sums[2 * v], l1);
         atomicAdd(&a.sums[2 * v + 1], ssum);
     }
 }
 
-// Pass B: grid (ceil(W/32), ceil(H/32), V*3), block 256.
-__global__ __launch_bounds__(256) void ggs_k_loss_grad(LossArgs a) {
-    __shared__ float sd[3][LI][LI + 1];
-    __shared__ float hh[3][LI][LT + 1];
-    const int tid = threadIdx.x;
-    const int v = blockIdx.z / 3, ch = blockIdx.z % 3;
-    const int ox = blockIdx.x * LT, oy = blockIdx.y * LT;
-    const size_t HW = (size_t)a.H * a.W;
-    const float* dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW;
-    {   // all global loads of a thread in flight at once (see pass A)
-        constexpr int NL = (LI * LI + 255) / 256;
-        float d0[NL], d1[NL], d2[NL];
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int i = tid + j * 256;
-            const int r = i / LI, c = i % LI;
-            const int y = oy + r - LH, x = ox + c - LH;
-            const bool in = i < LI * LI && x >= 0 && x < a.W && y >= 0 && y < a.H;
-            const size_t p = in ? (size_t)y * a.W + x : 0;
-            d0[j] = in ? dm[p] : 0.f; d1[j] = in ? dm[HW + p] : 0.f; d2[j] = in ? dm[2 * HW + p] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < NL; ++j) {
-            const int i = tid + j * 256;
-            if (i >= LI * LI) continue;
-            const int r = i / LI, c = i % LI;
-            sd[0][r][c] = d0[j]; sd[1][r][c] = d1[j]; sd[2][r][c] = d2[j];
-        }
+}  // namespace
+
+// Pass A: grid (ceil(W/64), ceil(ceil(H/34)/4), V*3), block 256 = 4 independent waves.
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ggs_k_loss_stats(LossArgs a) {
+    __shared__ float s_x[LS_WAVES][2][LS_IN], s_y[LS_WAVES][2][LS_IN];
+    __shared__ float s_red[4];
+    if (a.mask) loss_stats_stream_body<true>(a, s_x, s_y, s_red);
+    else loss_stats_stream_body<false>(a, s_x, s_y, s_red);
+}
+
+namespace {
+
+// next input row of the three derivative maps + the image values at the NEXT output pixel (consumed one step later)
+struct GradRow { float a1, b1, c1, a2, b2, c2, xo, yo, mo; bool ok1, ok2; };
+template <bool MASK>
+__device__ __forceinline__ GradRow grad_load_row(const float* __restrict__ dm, const float* __restrict__ img,
+                                                const float* __restrict__ gt, const float* __restrict__ mask, size_t HW,
+                                                int y, int yo, int H, int W, int ox, int lane) {
+    const RowAddr ad = row_addr(y, H, W, ox, lane);
+    GradRow r;
+    r.ok1 = ad.ok1; r.ok2 = ad.ok2;
+    r.a1 = dm[ad.p1]; r.b1 = dm[HW + ad.p1]; r.c1 = dm[2 * HW + ad.p1];
+    r.a2 = dm[ad.p2]; r.b2 = dm[HW + ad.p2]; r.c2 = dm[2 * HW + ad.p2];
+    const size_t po = (size_t)min(max(yo, 0), H - 1) * W + min(ox + lane, W - 1);
+    r.xo = img[po]; r.yo = gt[po]; r.mo = MASK ? mask[po] : 1.f;
+    return r;
+}
+struct GradCtx {
+    const float *img, *gt, *mask, *dm;
+    float* out;
+    int H, W, oy, ox, lane;
+    size_t HW;
+    float w_l1, w_ssim;
+    float (*sd)[3][LS_IN];    // [2][3][LS_IN] wave-private
+    GradRow nxt;
+    float o0;
+    bool pend;
+};
+template <int R, bool MASK>
+__device__ __forceinline__ void grad_step(GradCtx& c, RowRing<3>& ring, int i) {
+    const int buf = i & 1, lane = c.lane;
+    const int x = c.ox + lane;
+    c.sd[buf][0][lane] = c.nxt.ok1 ? c.nxt.a1 : 0.f; c.sd[buf][1][lane] = c.nxt.ok1 ? c.nxt.b1 : 0.f;
+    c.sd[buf][2][lane] = c.nxt.ok1 ? c.nxt.c1 : 0.f;
+    if (lane < 2 * LH) {
+        c.sd[buf][0][LS_COLS + lane] = c.nxt.ok2 ? c.nxt.a2 : 0.f; c.sd[buf][1][LS_COLS + lane] = c.nxt.ok2 ? c.nxt.b2 : 0.f;
+        c.sd[buf][2][LS_COLS + lane] = c.nxt.ok2 ? c.nxt.c2 : 0.f;
     }
-    __syncthreads();
-    {   // horizontal, register blocked like pass A
-        const int r = tid >> 2, c0 = (tid & 3) * 8;
-        if (r < LI) {
-            float d[3][18];
+    const float xo = c.nxt.xo, yo = c.nxt.yo, mo = c.nxt.mo;          // image at this step's output pixel
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (c.pend) c.out[(size_t)(c.oy + i - 1 - 2 * LH) * c.W + x] = c.o0;
+    c.nxt = grad_load_row<MASK>(c.dm, c.img, c.gt, c.mask, c.HW, c.oy - LH + i + 1, c.oy + i + 1 - 2 * LH, c.H, c.W, c.ox, lane);
+    float d[3][11];
 #pragma unroll
-            for (int m = 0; m < 3; ++m)
+    for (int m = 0; m < 3; ++m)
 #pragma unroll
-                for (int j = 0; j < 18; ++j) d[m][j] = sd[m][r][c0 + j];
+        for (int k = 0; k < 11; ++k) d[m][k] = c.sd[buf][m][lane + k];
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float h[3] = {0.f, 0.f, 0.f};
 #pragma unroll
-            for (int o = 0; o < 8; ++o) {
-                float h0 = 0.f, h1 = 0.f, h2 = 0.f;
-#pragma unroll
-                for (int k = 0; k < 11; ++k) {
-                    const float g = G11[k];
-                    h0 = fmaf(g, d[0][o + k], h0); h1 = fmaf(g, d[1][o + k], h1); h2 = fmaf(g, d[2][o + k], h2);
-                }
-                hh[0][r][c0 + o] = h0; hh[1][r][c0 + o] = h1; hh[2][r][c0 + o] = h2;
-            }
-        }
+    for (int k = 0; k < 11; ++k) {
+        const float g = G11[k];
+        h[0] = fmaf(g, d[0][k], h[0]); h[1] = fmaf(g, d[1][k], h[1]); h[2] = fmaf(g, d[2][k], h[2]);
     }
-    __syncthreads();
-    const float* img = a.img + ((size_t)v * 3 + ch) * HW;
-    const float* gt = a.gt + ((size_t)v * 3 + ch) * HW;
-    const float* mask = a.mask ? a.mask + (size_t)v * HW : nullptr;
-    float* out = a.dL_dimg + ((size_t)v * 3 + ch) * HW;
-    const float w_l1 = a.w[2 * v] * a.inv_n, w_ssim = a.w[2 * v + 1] * a.inv_n;
+    ring_add<3, R>(ring, h);
+    const int o = i - 2 * LH;
+    c.pend = o >= 0 && c.oy + o < c.H && x < c.W;
     {
-        const int c = tid & 31, r0 = (tid >> 5) * 4;
-        const int x = ox + c;
-        float col[3][14];
-#pragma unroll
-        for (int m = 0; m < 3; ++m)
-#pragma unroll
-            for (int j = 0; j < 14; ++j) col[m][j] = hh[m][r0 + j][c];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) {
-            const int y = oy + r0 + o;
-            if (x >= a.W || y >= a.H) continue;
-            float f0 = 0.f, f1 = 0.f, f2 = 0.f;
-#pragma unroll
-            for (int k = 0; k < 11; ++k) {
-                const float g = G11[k];
-                f0 = fmaf(g, col[0][o + k], f0); f1 = fmaf(g, col[1][o + k], f1); f2 = fmaf(g, col[2][o + k], f2);
-            }
-            const size_t p = (size_t)y * a.W + x;
-            const float m = mask ? mask[p] : 1.f;
-            const float xv = img[p] * m, yv = gt[p] * m;
-            const float dssim = f0 + 2.f * xv * f1 + yv * f2;
-            const float df = xv - yv;
-            const float dl1 = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-            out[p] = m * (w_ssim * dssim + w_l1 * dl1);
-        }
+        constexpr int slot = (R + 1) % 11;
+        const float f0 = ring.v[slot][0], f1 = ring.v[slot][1], f2 = ring.v[slot][2];
+        const float xv = xo * mo, yv = yo * mo;
+        const float dssim = f0 + 2.f * xv * f1 + yv * f2;
+        const float df = xv - yv;
+        const float dl1 = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
+        c.o0 = mo * (c.w_ssim * dssim + c.w_l1 * dl1);
     }
+}
+template <bool MASK>
+struct GradStep {
+    template <int R> static __device__ __forceinline__ void run(GradCtx& c, RowRing<3>& r, int i) { grad_step<R, MASK>(c, r, i); }
+};
+
+template <bool MASK>
+__device__ __forceinline__ void loss_grad_stream_body(const LossArgs& a, float (*s_d)[2][3][LS_IN]) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    const int v = blockIdx.z / 3, ch = blockIdx.z % 3;
+    const int band = blockIdx.y * LS_WAVES + wave;
+    const size_t HW = (size_t)a.H * a.W;
+    GradCtx c;
+    c.img = a.img + ((size_t)v * 3 + ch) * HW; c.gt = a.gt + ((size_t)v * 3 + ch) * HW;
+    c.mask = MASK ? a.mask + (size_t)v * HW : nullptr;
+    c.dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW;
+    c.out = a.dL_dimg + ((size_t)v * 3 + ch) * HW;
+    c.H = a.H; c.W = a.W; c.oy = band * LS_HB; c.ox = blockIdx.x * LS_COLS; c.lane = lane; c.HW = HW;
+    c.w_l1 = a.w[2 * v] * a.inv_n; c.w_ssim = a.w[2 * v + 1] * a.inv_n;
+    c.sd = s_d[wave];
+    c.pend = false; c.o0 = 0.f;
+    if (c.oy >= a.H) return;
+    RowRing<3> ring;
+#pragma unroll
+    for (int j = 0; j < 11; ++j)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) ring.v[j][m] = 0.f;
+    c.nxt = grad_load_row<MASK>(c.dm, c.img, c.gt, c.mask, HW, c.oy - LH, c.oy - 2 * LH, c.H, c.W, c.ox, lane);
+    for (int i0 = 0; i0 < LS_HB + 2 * LH; i0 += 11) unroll11<0, GradStep<MASK>>(c, ring, i0);
+    if (c.pend) c.out[(size_t)(c.oy + LS_HB - 1) * c.W + c.ox + lane] = c.o0;
+}
+
+}  // namespace
+
+// Pass B: same decomposition as pass A.
+__global__ __launch_bounds__(256) void ggs_k_loss_grad(LossArgs a) {
+    __shared__ float s_d[LS_WAVES][2][3][LS_IN];
+    if (a.mask) loss_grad_stream_body<true>(a, s_d);
+    else loss_grad_stream_body<false>(a, s_d);
 }
 
 extern "C" {
@@ -295,7 +370,8 @@ int ggs_photometric_forward(int n_views, int H, int W, const float* img, const f
     a.sums = sums;
     if (ggs_zero_async(sums, (size_t)n_views * 2 * sizeof(float), s) != hipSuccess)
         return ggs_fail_(GGS_ERR_HIP, "ggs_photometric_forward: clearing the sums failed");
-    const dim3 grid((unsigned)((W + LT - 1) / LT), (unsigned)((H + LT - 1) / LT), (unsigned)n_views);
+    const int bands = (H + LS_HB - 1) / LS_HB;
+    const dim3 grid((unsigned)((W + LS_COLS - 1) / LS_COLS), (unsigned)((bands + LS_WAVES - 1) / LS_WAVES), (unsigned)(n_views * 3));
     hipLaunchKernelGGL(ggs_k_loss_stats, grid, dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "loss_stats launch failed: %s", hipGetErrorString(e));
@@ -309,7 +385,8 @@ int ggs_photometric_backward(int n_views, int H, int W, const float* img, const 
     if (rc != GGS_OK) return rc;
     if (!weights || !dL_dimg) return ggs_fail_(GGS_ERR_ARG, "ggs_photometric_backward: NULL pointer argument");
     a.w = weights; a.dL_dimg = dL_dimg;
-    const dim3 grid((unsigned)((W + LT - 1) / LT), (unsigned)((H + LT - 1) / LT), (unsigned)(n_views * 3));
+    const int bands = (H + LS_HB - 1) / LS_HB;
+    const dim3 grid((unsigned)((W + LS_COLS - 1) / LS_COLS), (unsigned)((bands + LS_WAVES - 1) / LS_WAVES), (unsigned)(n_views * 3));
     hipLaunchKernelGGL(ggs_k_loss_grad, grid, dim3(256), 0, (hipStream_t)stream_, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "loss_grad launch failed: %s", hipGetErrorString(e));
