@@ -1,0 +1,24 @@
+#!/bin/bash
+# Everything profiles/ holds for one round, from ONE build, in one GPU-box call:  tools/profile_round.sh r02
+# (run it through gpurun; the summaries land in gpurun_out/prof_<round>_*, the default bench line in
+# gpurun_out/<round>_bench_default.json -- copy both sets into profiles/ afterwards).
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+N=${1:-r02}
+cd $R
+WORKLOAD="100000 1920 1080 0" bash tools/profile_all.sh ${N}_sh0 --chunk 32
+WORKLOAD="100000 1920 1080 3" PASSES="trace sq fetch write" bash tools/profile_all.sh ${N}_sh3 --sh-degree 3 --chunk 32
+WORKLOAD="500000 3840 2160 3" PASSES="trace sq fetch write" bash tools/profile_all.sh ${N}_c5 --sh-degree 3 --n-around 500 --n-rows 500 --width 3840 --height 2160 --chunk 16 --views 32
+ONLY_TRACE=1 bash tools/profile_all.sh ${N}_v20 --views 20 --chunk 20
+WORKLOAD="100000 1920 1080 0" PMC_VIEWS=1 PASSES="trace sq fetch write" bash tools/profile_all.sh ${N}_v1 --views 1 --chunk 1 --no-graph
+# graph-replayed s2 step: where one iteration's GPU time goes
+cd /tmp && export TMPDIR=/tmp
+timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/gs -o g -- python $R/tools/profile_graph_step.py 64 > $R/gpurun_out/gs.log 2>&1
+python $R/tools/rocpd_summary.py $(find $R/gpurun_out/gs -name "*.db" | head -1) > $R/gpurun_out/prof_${N}_graph_step_kernels.md 2>&1
+grep "graphed s2 step" $R/gpurun_out/gs.log >> $R/gpurun_out/prof_${N}_graph_step_kernels.md
+rm -rf $R/gpurun_out/gs
+# the default bench line needs the traffic / VALU collections of THIS build in profiles/: copy them in on the box first
+cd $R
+for f in gpurun_out/prof_${N}_*; do cp $f profiles/$(basename $f | sed 's/^prof_//'); done
+python bench.py > gpurun_out/${N}_bench_default.json 2> gpurun_out/${N}_bench_default.err
+python tools/bench_next_rows.py > gpurun_out/prof_${N}_next_rows.md 2> gpurun_out/${N}_next_rows.err || true
+tail -c 400 gpurun_out/${N}_bench_default.json
