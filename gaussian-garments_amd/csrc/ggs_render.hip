@@ -201,10 +201,14 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
     __shared__ float4 s_rec[64 * 3];
     RoundLds lds{s_rec};
     if (L > 0) {
+        // id words two rounds ahead, records one round ahead (ggs_render_common.h): a lone wave would otherwise sit out the
+        // id load of every round before it can ask for the records (one view: 101 -> 94 us; the tile-wave mapping has other
+        // waves to run meanwhile and only pays for the extra register: left as it is)
         Rec3 nxt = gather_round(rec, ids, 0, L, lane);
+        uint32_t w_ahead = gather_ids(ids, 64, L, lane);
         for (int first = 0; first < L && remaining != 0; first += 64) {
             const Rec3 cur = nxt;
-            if (first + 64 < L) nxt = gather_round(rec, ids, first + 64, L, lane);
+            if (first + 64 < L) { nxt = gather_recs(rec, w_ahead); w_ahead = gather_ids(ids, first + 128, L, lane); }
             const int n = min(64, L - first);
             lds.put(cur, lane);
             // entries of the round that reach this quadrant, as a lane mask: the walk takes them two at a time and

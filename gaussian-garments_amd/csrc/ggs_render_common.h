@@ -76,17 +76,26 @@ __device__ __forceinline__ float sel(uint64_t m, float a, float b) {           /
 
 struct Rec3 { float4 a, b, c; uint32_t w; };   // record of splat (first + lane) and its id word
 
-__device__ __forceinline__ Rec3 gather_round(const float4* __restrict__ rec, const uint32_t* __restrict__ ids,
-                                             int first, int L, int lane) {
+// id word of list position (first + lane), clamped into the list
+__device__ __forceinline__ uint32_t gather_ids(const uint32_t* __restrict__ ids, int first, int L, int lane) {
     int i = first + lane;
     i = i < L ? i : L - 1;
     i = i < 0 ? 0 : i;
+    return ids[i];
+}
+__device__ __forceinline__ Rec3 gather_recs(const float4* __restrict__ rec, uint32_t w) {
     Rec3 o;
-    o.w = ids[i];
-    const float4* r = rec + (size_t)(o.w & GGS_ID_MASK) * 3;
+    o.w = w;
+    const float4* r = rec + (size_t)(w & GGS_ID_MASK) * 3;
     o.a = r[0]; o.b = r[1]; o.c = r[2];
     return o;
 }
+__device__ __forceinline__ Rec3 gather_round(const float4* __restrict__ rec, const uint32_t* __restrict__ ids,
+                                             int first, int L, int lane) {
+    return gather_recs(rec, gather_ids(ids, first, L, lane));
+}
+// The gather of a round is two dependent loads (id word -> record).  The latency-mapped forward keeps the id words TWO
+// rounds ahead and the records one round ahead.
 
 // The 64 records of a round are parked in a wave-private LDS slice and every splat is read back with
 // wave-uniform (broadcast) ds_read_b128: the LDS pipe issues beside the VALU, where 11 v_readlane per splat
