@@ -362,8 +362,9 @@ def main():
                 vj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 if vj.get("build_id") == bid and vj.get("workload") == {"P": Fn, "W": W, "H": H, "sh_degree": args.sh_degree}:
                     kv = vj["kernels"]["ggs_k_" + dom + ("_sh%d" % args.sh_degree if dom == "preprocess_bwd" else "")]
-                    valu = {"busy_pct": kv.get("rocprof_valu_busy_pct") or kv["valu_busy_pct"],
-                            "lane_activity_pct": kv.get("rocprof_lane_activity_pct") or kv["lane_activity_pct"], "source": "profiles/" + fn}
+                    valu = {"busy_pct": round(kv.get("rocprof_valu_busy_pct") or kv["valu_busy_pct"], 1),
+                            "lane_activity_pct": round(kv.get("rocprof_lane_activity_pct") or kv["lane_activity_pct"], 1),
+                            "source": "profiles/" + fn}
                     break
             except Exception:
                 continue
