@@ -23,7 +23,11 @@ def _ref(img, gt, mask, lam, wa=1.0, wb=1.0):
     return float(l_img), float(l_ssim), x.grad
 
 
-@pytest.mark.parametrize("H,W,use_mask", [(48, 64, True), (48, 64, False), (37, 53, True), (70, 33, False), (11, 9, True)])
+# the kernels stream 64-column strips in bands of 34 rows, four bands per workgroup: sizes on, one over and one under those
+# edges, one row / one column images, and a size with a partly idle last workgroup (137 rows = 5 bands)
+@pytest.mark.parametrize("H,W,use_mask", [(48, 64, True), (48, 64, False), (37, 53, True), (70, 33, False), (11, 9, True),
+                                          (34, 64, True), (35, 65, False), (33, 63, True), (137, 130, True), (1, 200, False),
+                                          (150, 1, True)])
 def test_fused_loss_matches_reference_restatement(H, W, use_mask):
     from ggsplat.loss import fused_photometric_loss
     g = torch.Generator().manual_seed(H * 100 + W)
