@@ -185,6 +185,47 @@ def test_one_view_against_the_c_oracle(scene):
     co.close()
 
 
+def test_eight_view_launch_against_the_c_oracle(scene):
+    """The launch shape bench.py times: EIGHT config-2 views in one call (= the one-wave-per-tile kernels; the one-view test
+    above runs the per-quadrant mapping), SH degree 0 features as in s2, gradients summed over the views -- against the C
+    oracle run view by view on the host and summed in float64."""
+    import numpy as np
+    from helpers import REL_L1_TOL, rel_l1
+    from oracle.c_oracle import COracle
+    from ggsplat import rasterizer as R
+    inp, _ = scene
+    P = inp["means3D"].shape[0]
+    g = torch.Generator().manual_seed(11)
+    shs = (torch.rand(P, 1, 3, generator=g) - 0.5) / 0.28209479177387814         # RGB2SH of uniform colours
+    w = torch.randn(3, H, W, generator=g)
+    cams = [S.rig_cameras()[i] for i in (3, 30, 41, 77, 90, 118, 133, 158)]      # all five rings, all sides
+    ck = S.stack_cameras(cams, device="cuda")
+    color, radii, depth, alpha, st = R.forward_views(
+        inp["means3D"], inp["opacities"], shs.cuda(), None, inp["scales"], inp["rotations"], None, view=ck["view"],
+        proj=ck["proj"], campos=ck["campos"], tanfov=ck["tanfov"], bg=torch.zeros(3, device="cuda"), W=W, H=H, sh_degree=0)
+    assert st.prm.n_views * ((W + 15) // 16) * ((H + 15) // 16) >= 57344       # above the per-quadrant mapping's threshold
+    gr = R.backward_views(st, w.cuda()[None].expand(len(cams), 3, H, W).contiguous(), want_means2D=True)
+    ci = {k: v.cpu() for k, v in inp.items()}
+    acc = {}
+    for vi, cam in enumerate(cams):
+        co = COracle(means3D=ci["means3D"], opacities=ci["opacities"], shs=shs, scales=ci["scales"], rotations=ci["rotations"],
+                     viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, campos=cam.camera_center,
+                     bg=torch.zeros(3), W=W, H=H, tanfovx=math.tan(cam.FoVx * 0.5), tanfovy=math.tan(cam.FoVy * 0.5),
+                     sh_degree=0)
+        og = co.backward(w)
+        assert np.array_equal(radii[vi].cpu().numpy(), co.radii), vi
+        assert rel_l1(color[vi].cpu(), co.color) <= REL_L1_TOL, vi
+        assert rel_l1(depth[vi].cpu(), co.depth.reshape(H, W)) <= REL_L1_TOL, vi
+        assert rel_l1(alpha[vi].cpu(), co.alpha.reshape(H, W)) <= REL_L1_TOL, vi
+        assert rel_l1(gr["means2D"][vi].cpu().reshape(og["means2D"].shape), og["means2D"]) <= REL_L1_TOL, vi
+        for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+            t = torch.as_tensor(og[k]).double()
+            acc[k] = t if k not in acc else acc[k] + t
+        co.close()
+    for k in ("means3D", "opacities", "shs", "scales", "rotations"):
+        assert rel_l1(gr[k].cpu().reshape(acc[k].shape), acc[k].float()) <= REL_L1_TOL, k
+
+
 def test_stress_config_view_against_the_c_oracle():
     """BASELINE config 5 (stress): ~500k Gaussians, 3840x2160, SH degree 3 -- one view against the C oracle."""
     import numpy as np
