@@ -384,7 +384,7 @@ def main():
                                    "frac": round(B_view * views_per_sec / 1e9 / HBM_PEAK_GBS, 5)}}
 
         # ---- per-view drop-in loop (render() + autograd, one camera per call like the reference) ----
-        loop_vps = step_vps = graph_vps = None
+        loop_vps = step_vps = graph_vps = s3_vps = None
         if args.loop_views > 0 and world == 1:
             from ggsplat.render import render
             from types import SimpleNamespace
@@ -441,6 +441,40 @@ def main():
             graph_recaptures = gstep.recaptures
             del gstep
             model.optimizer = None
+
+            # the s3 iteration in its config-4 form (s3_appearance.py:107-149): texel-bound Gaussians (barycentric origins),
+            # SH degree 3, ~50 % visible (mask applied to the opacities inside the captured step), get_final_xyz and SH
+            # offsets from a stand-in "net" (two parameter tensors: the StyleUNet itself is PyTorch-ROCm and out of scope),
+            # five-term loss, backward, guarded Adam over the net's and the Gaussians' parameters -- one hipGraph per iteration
+            from ggsplat.inner_step import GraphedAppearanceStep
+            g3 = torch.Generator().manual_seed(61)
+            bc = torch.rand(Fn, 3, generator=g3) + 0.05
+            m3 = MeshGaussianModel.from_tensors(verts, faces, S.skirt_gaussian_params(Fn, sh_degree=3), sh_degree=3, device=dev,
+                                                gs_bc=bc / bc.sum(1, keepdim=True))
+            vis3 = (torch.rand(Fn, generator=g3) > 0.5).to(dev)
+
+            class _Net(torch.nn.Module):
+                def __init__(self):
+                    super().__init__()
+                    self.xyz_off = torch.nn.Parameter((torch.randn(Fn, 3, generator=g3) * 0.002).to(dev))
+                    self.sh_off = torch.nn.Parameter((torch.randn(Fn, 16, 3, generator=g3) * 0.03).to(dev))
+
+                def forward(self, gaussians, cam):
+                    return self.xyz_off, self.sh_off, vis3
+            net3 = _Net()
+            o3 = GraphAdam([{"params": [net3.xyz_off], "lr": 1e-4, "name": "net_xyz"}, {"params": [net3.sh_off], "lr": 2e-3, "name": "net_sh"},
+                            {"params": [m3._opacity], "lr": 1e-2, "name": "opacity"}, {"params": [m3._scaling], "lr": 2e-3, "name": "scaling"},
+                            {"params": [m3._features_dc], "lr": 2.5e-3, "name": "f_dc"}], lr=0.0, eps=1e-15)
+            s3step = GraphedAppearanceStep(m3, net3, W, H, bg, o3)
+            for c in lcams[:2]:
+                s3step(c, gt_img, gt_mask)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for c in lcams:
+                s3step(c, gt_img, gt_mask)
+            torch.cuda.synchronize(dev)
+            s3_vps = len(lcams) / (time.perf_counter() - t1)
+            del s3step, m3, net3, o3
 
         # ---- CPU baseline: the C oracle on the host cores, bounded sample of the same views ----
         cpu = None
@@ -513,6 +547,7 @@ def main():
             "per_view_loop_views_per_sec": None if loop_vps is None else round(loop_vps, 2),
             "s2_inner_step_iters_per_sec": None if step_vps is None else round(step_vps, 2),
             "s2_graph_step_iters_per_sec": None if graph_vps is None else round(graph_vps, 2),
+            "s3_graph_step_iters_per_sec": None if s3_vps is None else round(s3_vps, 2),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

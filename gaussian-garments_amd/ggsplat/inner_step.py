@@ -247,9 +247,13 @@ class GraphedRegistrationStep:
     def _capture(self):
         g = self.g
         # eager warm-up on a side stream: learns the binning capacity, leaves parameters and statistics alone
+        import warnings
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
+        with torch.cuda.stream(s), warnings.catch_warnings():
+            # the warm-up runs on a side stream as torch.cuda.graph's documentation prescribes; leaves created on the
+            # default stream make autograd note the stream change -- expected here, and the grads are dropped right after
+            warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")
             self._body(optimizer_step=False, track=False)
             self.optimizer.zero_grad()
         torch.cuda.current_stream().wait_stream(s)
