@@ -262,7 +262,8 @@ class GraphedRegistrationStep:
             R.grow_capacity(self._slack)
             self._slack = 1.0
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph), warnings.catch_warnings():
+            warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")   # capture stream
             out = self._body(optimizer_step=True, track=self.track)
             self._hdr_dev = R.last_header()
         self.out = {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
