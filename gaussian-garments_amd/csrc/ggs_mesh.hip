@@ -168,12 +168,36 @@ __global__ __launch_bounds__(256) void k_mesh_fwd(MeshArgs a) {
     reinterpret_cast<float4*>(a.rotation)[i] = make_float4(Q.rot[0], Q.rot[1], Q.rot[2], Q.rot[3]);
 }
 
+// Vertex gradients: the 256 Gaussians of a workgroup are neighbours on the mesh, so the vertices they touch usually span a
+// short index range.  Their 9 contributions each are summed in an LDS window over that range (ds_add_f32) and the window is
+// flushed with ONE global atomic per touched component: 100k Gaussians on a 50k-vertex grid send ~0.9 M global atomics with
+// ~6 writers per address otherwise, which was this kernel's whole duration (30 us; the arithmetic is ~3 us).  A range
+// wider than the window (unstructured bindings) falls back to the direct atomics.
+#define MESH_WIN 2048            // vertices -> 24 KB of LDS
 __global__ __launch_bounds__(256) void k_mesh_bwd(MeshArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.P) return;
+    __shared__ float s_win[MESH_WIN * 3];
+    __shared__ int s_rng[2];
+    const int i0 = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i0 < a.P;
+    const int i = live ? i0 : a.P - 1;            // idle lanes shadow the last Gaussian and write nothing
     Frame F;
     int64_t idx[3];
     face_frame(a.verts, a.faces, a.binding[i], F, idx);
+    if (threadIdx.x == 0) { s_rng[0] = 0x7fffffff; s_rng[1] = -1; }
+    __syncthreads();
+    {
+        int lo = (int)min(idx[0], min(idx[1], idx[2])), hi = (int)max(idx[0], max(idx[1], idx[2]));
+        if (!live) { lo = 0x7fffffff; hi = -1; }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { lo = min(lo, __shfl_xor(lo, d)); hi = max(hi, __shfl_xor(hi, d)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&s_rng[0], lo); atomicMax(&s_rng[1], hi); }
+    }
+    __syncthreads();
+    const int vbase = s_rng[0], vcount = s_rng[1] - s_rng[0] + 1;
+    const bool windowed = vcount > 0 && vcount <= MESH_WIN;
+    if (windowed)
+        for (int j = threadIdx.x; j < 3 * vcount; j += 256) s_win[j] = 0.f;
+    __syncthreads();
     const V3 l = ld3(a.local_xyz + 3 * (size_t)i);
     const V3 dxyz = a.dL_dxyz ? ld3(a.dL_dxyz + 3 * (size_t)i) : V3{0.f, 0.f, 0.f};
     const V3 dsc = a.dL_dscaling ? ld3(a.dL_dscaling + 3 * (size_t)i) : V3{0.f, 0.f, 0.f};
@@ -200,7 +224,7 @@ __global__ __launch_bounds__(256) void k_mesh_bwd(MeshArgs a) {
     dqr[2] = -dqw[0] * A[2] - dqw[1] * A[3] + dqw[2] * A[0] + dqw[3] * A[1];
     dqr[3] = -dqw[0] * A[3] + dqw[1] * A[2] - dqw[2] * A[1] + dqw[3] * A[0];
     normalize4_vjp(Q.qr, Q.qrn, dqr, draw);
-    reinterpret_cast<float4*>(a.dL_draw_rot)[i] = make_float4(draw[0], draw[1], draw[2], draw[3]);
+    if (live) reinterpret_cast<float4*>(a.dL_draw_rot)[i] = make_float4(draw[0], draw[1], draw[2], draw[3]);
     normalize4_vjp(Q.qf, Q.qfn, dqf, dqf0);
     // qf0 (wxyz) = u (xyzw) / |u|
     const float dq_xyzw[4] = {dqf0[1], dqf0[2], dqf0[3], dqf0[0]};
@@ -229,13 +253,15 @@ __global__ __launch_bounds__(256) void k_mesh_bwd(MeshArgs a) {
     const V3 dw = dxyz * F.s;
     float ds = dot(dxyz, w);
     da0 = da0 + dw * l.x; da1 = da1 + dw * l.y; da2 = da2 + dw * l.z;
-    a.dL_dlocal[3 * (size_t)i] = dot(dw, F.a0);
-    a.dL_dlocal[3 * (size_t)i + 1] = dot(dw, F.a1);
-    a.dL_dlocal[3 * (size_t)i + 2] = dot(dw, F.a2);
+    if (live) {
+        a.dL_dlocal[3 * (size_t)i] = dot(dw, F.a0);
+        a.dL_dlocal[3 * (size_t)i + 1] = dot(dw, F.a1);
+        a.dL_dlocal[3 * (size_t)i + 2] = dot(dw, F.a2);
+    }
     const float dscv[3] = {dsc.x, dsc.y, dsc.z};
     for (int k = 0; k < 3; ++k) {
         const float ex = expf(a.log_scaling[3 * (size_t)i + k]);
-        a.dL_dlog_scaling[3 * (size_t)i + k] = dscv[k] * ex * F.s;
+        if (live) a.dL_dlog_scaling[3 * (size_t)i + k] = dscv[k] * ex * F.s;
         ds += dscv[k] * ex;
     }
     // s = (l1 + |a2.e2|) / 2
@@ -265,12 +291,29 @@ __global__ __launch_bounds__(256) void k_mesh_bwd(MeshArgs a) {
         const V3 t = dxyz * (1.f / 3.f);
         g0 = g0 + t; g1 = g1 + t; g2 = g2 + t;
     }
-    float* o0 = a.dL_dverts + 3 * idx[0];
-    float* o1 = a.dL_dverts + 3 * idx[1];
-    float* o2 = a.dL_dverts + 3 * idx[2];
-    atomicAdd(o0, g0.x); atomicAdd(o0 + 1, g0.y); atomicAdd(o0 + 2, g0.z);
-    atomicAdd(o1, g1.x); atomicAdd(o1 + 1, g1.y); atomicAdd(o1 + 2, g1.z);
-    atomicAdd(o2, g2.x); atomicAdd(o2 + 1, g2.y); atomicAdd(o2 + 2, g2.z);
+    if (windowed) {
+        if (live) {
+            float* o0 = s_win + 3 * (int)(idx[0] - vbase);
+            float* o1 = s_win + 3 * (int)(idx[1] - vbase);
+            float* o2 = s_win + 3 * (int)(idx[2] - vbase);
+            atomicAdd(o0, g0.x); atomicAdd(o0 + 1, g0.y); atomicAdd(o0 + 2, g0.z);
+            atomicAdd(o1, g1.x); atomicAdd(o1 + 1, g1.y); atomicAdd(o1 + 2, g1.z);
+            atomicAdd(o2, g2.x); atomicAdd(o2 + 1, g2.y); atomicAdd(o2 + 2, g2.z);
+        }
+        __syncthreads();
+        float* out = a.dL_dverts + 3 * (size_t)vbase;
+        for (int j = threadIdx.x; j < 3 * vcount; j += 256) {
+            const float v = s_win[j];
+            if (v != 0.f) atomicAdd(out + j, v);
+        }
+    } else if (live) {
+        float* o0 = a.dL_dverts + 3 * idx[0];
+        float* o1 = a.dL_dverts + 3 * idx[1];
+        float* o2 = a.dL_dverts + 3 * idx[2];
+        atomicAdd(o0, g0.x); atomicAdd(o0 + 1, g0.y); atomicAdd(o0 + 2, g0.z);
+        atomicAdd(o1, g1.x); atomicAdd(o1 + 1, g1.y); atomicAdd(o1 + 2, g1.z);
+        atomicAdd(o2, g2.x); atomicAdd(o2 + 1, g2.y); atomicAdd(o2 + 2, g2.z);
+    }
 }
 
 }  // namespace
