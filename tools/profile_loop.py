@@ -24,3 +24,4 @@ t = time.perf_counter(); loop(); torch.cuda.synchronize(); dt = time.perf_counte
 print(f"per-view loop: {len(cams)/dt:.1f} views/s, {dt/len(cams)*1e3:.3f} ms/view")
 pr = cProfile.Profile(); pr.enable(); loop(); torch.cuda.synchronize(); pr.disable()
 pstats.Stats(pr).sort_stats("cumulative").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(28)
