@@ -137,60 +137,6 @@ Dims dims(const GgsParams* p) {
     return d;
 }
 
-// Segment length of the segment-parallel compositing (ggs_render_seg.hip), 0 = off.  Meant for the latency mapping (launches
-// with fewer than GGS_QUAD_ITEMS work items), where a launch is bounded by the serial walk of its longest tile list.
-// OFF by default: measured on MI355X (profiles/r02_segments.md) it bounds the longest chain as designed but does not shorten
-// the launch at config 2 (one 1080p view: forward 98 us unsegmented vs 39 + 71 + 10 us for the three passes at 128 entries
-// per segment; backward 93 vs 98 us) -- a lone wave advances ~800 cycles per list entry whatever the mapping, and what the
-// extra waves gain in parallelism the two extra passes and their launches take back.  It wins on the backward of very
-// long lists (config 5, one 4K view: 235 -> 187 us).  Knobs: GGS_SEG=1 switches it on, GGS_SEG_LEN sets the length (a
-// multiple of 64, default 128), GGS_SEG_QUAD=0 uses one wave per segment instead of per (segment, quadrant),
-// ggs_set_seg_len() overrides both at run time (tests).
-int g_seg_override = -1;           // ggs_set_seg_len(): -1 = environment / default
-int seg_len_for(const GgsParams* p) {
-    static const int env_len = [] {
-        const char* on = getenv("GGS_SEG");
-        if (!(on && *on && atoi(on) != 0)) return 0;
-        const char* e = getenv("GGS_SEG_LEN");
-        int v = e && *e ? atoi(e) : 128;
-        v = (v + 63) / 64 * 64;
-        return v < 64 ? 64 : v;
-    }();
-    static const int env_big = [] {          // large launches: cut only the heaviest lists (0 = off)
-        const char* e = getenv("GGS_SEG_BIG_LEN");
-        int v = e && *e ? atoi(e) : 0;
-        return v <= 0 ? 0 : (v + 63) / 64 * 64;
-    }();
-    const int len = g_seg_override >= 0 ? g_seg_override : env_len;
-    const Dims d = dims(p);
-    return (size_t)p->n_views * d.T < (size_t)GGS_QUAD_ITEMS ? len : env_big;
-}
-
-// one wave per (segment, quadrant) [1] or per segment with 4 pixels per lane [0]  (tuning knob GGS_SEG_QUAD)
-bool seg_quad() {
-    static const bool v = [] {
-        const char* e = getenv("GGS_SEG_QUAD");
-        return e && *e ? atoi(e) != 0 : true;
-    }();
-    return v;
-}
-
-SegInfo seg_info(const GgsParams* p, const BinLayout& L, char* bin, char* img) {
-    SegInfo s;
-    memset(&s, 0, sizeof(s));
-    s.seg_len = seg_len_for(p);
-    if (!s.seg_len) return s;
-    const size_t HW = (size_t)p->W * p->H;
-    s.max_vitems = (uint32_t)L.max_vitems; s.max_multi = (uint32_t)L.max_multi;
-    s.vitem = (uint2*)(bin + L.vitem);
-    s.seg_slot = (uint32_t*)(bin + L.seg_slot);
-    s.counts = (uint32_t*)(bin + L.header + GGS_SEG_COUNTS_OFF);
-    s.mitem = (uint32_t*)(bin + L.mitem);
-    s.seg_T = (float*)(img + 2 * ggs_align((size_t)p->n_views * HW * 4));
-    s.part = s.seg_T + L.max_slots * 256;
-    return s;
-}
-
 }  // namespace
 
 extern "C" {
@@ -204,12 +150,6 @@ const char* ggs_build_id(void) { return GGS_SRC_HASH; }
 
 int ggs_profile_enable(int on) { g_prof.on = on != 0; return GGS_OK; }
 
-int ggs_set_seg_len(int len) {
-    const int prev = g_seg_override;
-    g_seg_override = len < 0 ? -1 : (len == 0 ? 0 : (len + 63) / 64 * 64);
-    return prev;
-}
-
 int ggs_profile_read(float* ms, int n) {
     if (!ms || n < K_COUNT) return fail(GGS_ERR_ARG, "ggs_profile_read: need room for %d floats", (int)K_COUNT);
     for (int i = 0; i < K_COUNT; ++i) ms[i] = g_prof.ms[i];
@@ -222,10 +162,9 @@ int ggs_workspace_sizes(const GgsParams* p, size_t bin_capacity, size_t* geom_by
     const Dims d = dims(p);
     const size_t V = (size_t)p->n_views;
     if (geom_bytes) *geom_bytes = ggs_align(V * (size_t)p->P * sizeof(SplatRec)) + ggs_align(V * (size_t)p->P * sizeof(SplatAux));
-    const int seg = seg_len_for(p);
-    const BinLayout L = ggs_bin_layout(p->n_views, d.T, bin_capacity, seg);
-    // img: final_T | n_contrib | (segmented launches) per-slot transmittance factors and partial sums
-    if (img_bytes) *img_bytes = ggs_align(V * (size_t)p->W * p->H * 4) * 2 + ggs_align(L.max_slots * (1 + GGS_SEG_FIELDS) * 256 * sizeof(float));
+    const BinLayout L = ggs_bin_layout(p->n_views, d.T, bin_capacity);
+    // img: final_T | n_contrib
+    if (img_bytes) *img_bytes = ggs_align(V * (size_t)p->W * p->H * 4) * 2;
     if (bin_bytes) *bin_bytes = L.total;
     return GGS_OK;
 }
@@ -291,9 +230,8 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
     hipStream_t s = (hipStream_t)stream_;
     const Dims d = dims(p);
     const int V = p->n_views;
-    const BinLayout L = ggs_bin_layout(V, d.T, bin_capacity, seg_len_for(p));
+    const BinLayout L = ggs_bin_layout(V, d.T, bin_capacity);
     char* b = (char*)bin;
-    const SegInfo seg = seg_info(p, L, b, (char*)img);
     GgsBinHeader* header = (GgsBinHeader*)(b + L.header);
     uint32_t* tile_count = (uint32_t*)(b + L.tile_count);
     uint32_t* tile_cursor = (uint32_t*)(b + L.tile_cursor);
@@ -342,12 +280,6 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
         hipLaunchKernelGGL(ggs_k_order_tiles, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, o);
         prof_stop(K_ORDER, s);
         GGS_TRY(check("order_tiles", s, p->debug));
-        if (seg.seg_len) {
-            SegItemsArgs si;
-            si.n_items = n_items; si.order = order; si.tile_count = tile_count; si.header = header; si.seg = seg;
-            hipLaunchKernelGGL(ggs_k_seg_items, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, si);
-            GGS_TRY(check("seg_items", s, p->debug));
-        }
     }
     }  // PHASE_COUNT
     if (!(phases & PHASE_RENDER)) { prof_collect(s); return GGS_OK; }
@@ -384,21 +316,9 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
         a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.header = header;
         a.n_items = n_items; a.order = order; a.tile_count = tile_count; a.tile_offset = tile_offset; a.view_base = view_base; a.ids = ids;
         a.rec = (const SplatRec*)geom; a.bg = bg; a.out_color = out_color; a.out_depth = out_depth;
-        a.out_alpha = out_alpha; a.final_T = final_T; a.n_contrib = n_contrib; a.seg = seg;
+        a.out_alpha = out_alpha; a.final_T = final_T; a.n_contrib = n_contrib;
         prof_start(K_RENDER_FWD, s);
-        // small launches (a single view): the walk of a tile list is spread over one wave per (list segment, quadrant) --
-        // transmittance factors, compositing from the product of the factors in front, ordered sum of the partials
-        if (seg.seg_len && seg_quad() && n_items < GGS_QUAD_ITEMS) {
-            const dim3 gv((unsigned)seg.max_vitems), gm((unsigned)seg.max_multi);      // 4 waves (quadrants) per workgroup
-            hipLaunchKernelGGL(ggs_k_seg_trans_quad, gv, dim3(256), 0, s, a);
-            hipLaunchKernelGGL(ggs_k_seg_fwd_quad, gv, dim3(256), 0, s, a);
-            hipLaunchKernelGGL(ggs_k_seg_combine_quad, gm, dim3(256), 0, s, a);
-        } else if (seg.seg_len) {
-            const dim3 gv((unsigned)((seg.max_vitems + 3) / 4)), gm((unsigned)((seg.max_multi + 3) / 4));
-            hipLaunchKernelGGL(ggs_k_seg_trans, gv, dim3(256), 0, s, a);
-            hipLaunchKernelGGL(ggs_k_seg_fwd, gv, dim3(256), 0, s, a);
-            hipLaunchKernelGGL(ggs_k_seg_combine, gm, dim3(256), 0, s, a);
-        } else if (n_items < GGS_QUAD_ITEMS) hipLaunchKernelGGL(ggs_k_render_fwd_quad, dim3((unsigned)n_items * 4), dim3(64), 0, s, a);
+        if (n_items < GGS_QUAD_ITEMS) hipLaunchKernelGGL(ggs_k_render_fwd_quad, dim3((unsigned)n_items * 4), dim3(64), 0, s, a);
         else hipLaunchKernelGGL(ggs_k_render_fwd, dim3((unsigned)n_items), dim3(64), 0, s, a);
         prof_stop(K_RENDER_FWD, s);
         GGS_TRY(check("render_fwd", s, p->debug));
@@ -446,10 +366,9 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
     hipStream_t s = (hipStream_t)stream_;
     const Dims d = dims(p);
     const int V = p->n_views;
-    const BinLayout L = ggs_bin_layout(V, d.T, bin_capacity, seg_len_for(p));
+    const BinLayout L = ggs_bin_layout(V, d.T, bin_capacity);
     const char* b = (const char*)bin;
     const size_t HW = (size_t)p->W * p->H;
-    const SegInfo seg = seg_info(p, L, (char*)bin, (char*)img);      // read-only here
 
     if (ggs_zero_async(scratch, (size_t)V * p->P * sizeof(GradRec), s) != hipSuccess)
         return fail(GGS_ERR_HIP, "ggs_backward: clearing the gradient records failed: %s", hipGetErrorString(hipGetLastError()));
@@ -468,19 +387,10 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
         a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth; a.dL_dalpha = dL_dalpha;
         a.acc = (GradRec*)scratch;
         a.header = (const GgsBinHeader*)(b + L.header);
-        a.seg = seg;
         const dim3 gridT((unsigned)(V * d.T));   // one wave64 per (view, tile) work item, longest lists first
         prof_start(K_RENDER_BWD, s);
         const bool da = dL_ddepth || dL_dalpha;
-        if (seg.seg_len && seg_quad() && a.n_items < GGS_QUAD_ITEMS) {
-            const dim3 gv((unsigned)seg.max_vitems);
-            if (da) hipLaunchKernelGGL(ggs_k_seg_bwd_da_quad, gv, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(ggs_k_seg_bwd_quad, gv, dim3(256), 0, s, a);
-        } else if (seg.seg_len) {
-            const dim3 gv((unsigned)((seg.max_vitems + 3) / 4));
-            if (da) hipLaunchKernelGGL(ggs_k_seg_bwd_da, gv, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL(ggs_k_seg_bwd, gv, dim3(256), 0, s, a);
-        } else if (a.n_items < GGS_QUAD_ITEMS) {
+        if (a.n_items < GGS_QUAD_ITEMS) {
             const dim3 gridQ((unsigned)(a.n_items * 4));
             if (da) hipLaunchKernelGGL(ggs_k_render_bwd_da_quad, gridQ, dim3(64), 0, s, a);
             else hipLaunchKernelGGL(ggs_k_render_bwd_quad, gridQ, dim3(64), 0, s, a);

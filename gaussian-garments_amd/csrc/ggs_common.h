@@ -81,14 +81,11 @@ static_assert(sizeof(GradRec) == 48, "GradRec must be 48 bytes");
 struct BinLayout {               // byte offsets inside the binning buffer
     size_t header, tile_count, tile_cursor, tile_offset, view_base, order, keys, ids, total;
     size_t zero_bytes;           // header + tile_count + tile_cursor are cleared each forward
-    size_t seg_slot, vitem, mitem;       // segment-parallel compositing (seg_len > 0), behind ids
-    size_t max_vitems, max_multi, max_slots;
 };
-#define GGS_SEG_COUNTS_OFF 192    // byte offset of {n_vitems, n_slots, n_multi} inside the header region
 
 static inline size_t ggs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static inline BinLayout ggs_bin_layout(int V, int T, size_t cap, int seg_len = 0) {
+static inline BinLayout ggs_bin_layout(int V, int T, size_t cap) {
     BinLayout L;
     size_t o = 0;
     L.header = o;      o += ggs_align(sizeof(GgsBinHeader));
@@ -100,18 +97,6 @@ static inline BinLayout ggs_bin_layout(int V, int T, size_t cap, int seg_len = 0
     L.order = o;       o += ggs_align((size_t)V * T * 4);
     L.keys = o;        o += ggs_align(cap * 8);
     L.ids = o;         o += ggs_align(cap * 4);
-    L.seg_slot = L.vitem = L.mitem = o;
-    L.max_vitems = L.max_multi = L.max_slots = 0;
-    if (seg_len > 0) {
-        // sum over tiles of max(1, ceil(L / seg_len)) <= n_items + N / seg_len; a tile with > 1 segment has L > seg_len,
-        // so there are at most N / seg_len of them and they own at most 2 N / seg_len slots (N <= cap)
-        L.max_vitems = (size_t)V * T + cap / seg_len + 1;
-        L.max_multi = cap / seg_len + 1;
-        L.max_slots = 2 * (cap / seg_len) + 2;
-        L.seg_slot = o; o += ggs_align((size_t)V * T * 4);
-        L.vitem = o;    o += ggs_align(L.max_vitems * 8);
-        L.mitem = o;    o += ggs_align(L.max_multi * 4);
-    }
     L.total = o;
     return L;
 }

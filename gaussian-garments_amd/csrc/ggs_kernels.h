@@ -54,30 +54,6 @@ struct SortArgs {
     uint32_t* ids;
 };
 
-// Segment-parallel compositing (ggs_render_seg.hip): a tile list longer than seg_len is cut into segments of seg_len entries
-// that are composited by different waves.  Work items = "virtual items" (item, segment); tiles with more than one segment own
-// ceil(L / seg_len) consecutive partial SLOTS.
-#define GGS_SEG_FIELDS 7          // per (slot, pixel): colour r g b, depth, alpha, T at the end of the segment (-1: the pixel
-                                  // had already terminated when the segment started), last contributor (u32 bits)
-struct SegInfo {
-    int seg_len;                  // 0: not segmented
-    uint32_t max_vitems, max_multi;
-    uint2* vitem;                 // [max_vitems] (item, segment)
-    uint32_t* seg_slot;           // [n_items] first slot of the item (items with > 1 segment)
-    uint32_t* counts;             // {n_vitems, n_slots, n_multi}
-    uint32_t* mitem;              // [max_multi] items with > 1 segment
-    float* seg_T;                 // [slots][256] transmittance product of the segment alone (no termination rule)
-    float* part;                  // [slots][GGS_SEG_FIELDS][256]
-};
-
-struct SegItemsArgs {
-    int n_items;
-    const uint32_t* order;
-    const uint32_t* tile_count;
-    const GgsBinHeader* header;
-    SegInfo seg;
-};
-
 struct RenderArgs {
     int P, W, H, gx, gy, T, n_items;
     const uint32_t* order;
@@ -93,7 +69,6 @@ struct RenderArgs {
     float* out_alpha;         // [V][H][W]
     float* final_T;           // [V][H][W]
     uint32_t* n_contrib;      // [V][H][W]
-    SegInfo seg;
 };
 
 struct RenderBwdArgs {
@@ -113,7 +88,6 @@ struct RenderBwdArgs {
     const float* dL_dalpha;   // [V][H][W] or null
     GradRec* acc;             // [V][P]
     const GgsBinHeader* header;   // overflow != 0: the forward did not composite -> the backward does nothing
-    SegInfo seg;
 };
 
 struct PreBwdArgs {
@@ -140,17 +114,6 @@ __global__ void ggs_k_render_bwd(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_da(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_quad(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_da_quad(RenderBwdArgs a);
-__global__ void ggs_k_seg_items(SegItemsArgs a);
-__global__ void ggs_k_seg_trans(RenderArgs a);
-__global__ void ggs_k_seg_trans_quad(RenderArgs a);
-__global__ void ggs_k_seg_fwd(RenderArgs a);
-__global__ void ggs_k_seg_fwd_quad(RenderArgs a);
-__global__ void ggs_k_seg_combine(RenderArgs a);
-__global__ void ggs_k_seg_combine_quad(RenderArgs a);
-__global__ void ggs_k_seg_bwd(RenderBwdArgs a);
-__global__ void ggs_k_seg_bwd_da(RenderBwdArgs a);
-__global__ void ggs_k_seg_bwd_quad(RenderBwdArgs a);
-__global__ void ggs_k_seg_bwd_da_quad(RenderBwdArgs a);
 __global__ void ggs_k_preprocess_bwd_sh0(PreBwdArgs a);
 __global__ void ggs_k_preprocess_bwd_sh1(PreBwdArgs a);
 __global__ void ggs_k_preprocess_bwd_sh2(PreBwdArgs a);

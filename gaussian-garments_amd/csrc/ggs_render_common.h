@@ -1,5 +1,5 @@
-// ggs_render_common.h -- wave-level helpers shared by the compositing kernels (ggs_render.hip: one wave per tile /
-// per (tile, quadrant); ggs_render_seg.hip: one wave per (tile, list segment[, quadrant])).
+// ggs_render_common.h -- wave-level helpers of the compositing kernels (ggs_render.hip: one wave per tile /
+// per (tile, quadrant)).
 #pragma once
 #include "ggs_kernels.h"
 

@@ -62,7 +62,6 @@ _SIGS = {
     "ggs_last_error": (C.c_char_p, []),
     "ggs_version": (C.c_char_p, []),
     "ggs_build_id": (C.c_char_p, []),
-    "ggs_set_seg_len": (C.c_int, [C.c_int]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -99,7 +98,7 @@ def ptr(t):
     return t.data_ptr()             # ctypes converts the int for the void* parameters (no c_void_p object per argument)
 
 
-_SRC_ORDER = ("ggs_pergauss.hip", "ggs_binning.hip", "ggs_render.hip", "ggs_render_seg.hip", "ggs_mesh.hip", "ggs_loss.hip", "ggs_knn.hip",
+_SRC_ORDER = ("ggs_pergauss.hip", "ggs_binning.hip", "ggs_render.hip", "ggs_mesh.hip", "ggs_loss.hip", "ggs_knn.hip",
               "ggs_stylegan.hip", "ggs_visibility.hip", "ggs_adam.hip", "ggs_regaux.hip", "ggs_api.hip", "ggs_common.h",
               "ggs_kernels.h", "ggs_render_common.h", os.path.join("..", "..", "include", "ggsplat.h"), "Makefile")
 

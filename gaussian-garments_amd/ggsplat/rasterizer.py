@@ -63,13 +63,6 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 _ws_sizes: Dict[Tuple, Tuple[int, int, int]] = {}
 
 
-def set_segment_length(n: int) -> int:
-    """Segment length of the segment-parallel compositing of small launches (ggs_set_seg_len): a multiple of 64, 0 = off,
-    negative = default.  Clears the memoised workspace sizes, which depend on it.  Returns the previous override."""
-    _ws_sizes.clear()
-    return lib().ggs_set_seg_len(int(n))
-
-
 def _workspace_sizes(L, prm, cap: int) -> Tuple[int, int, int]:
     """ggs_workspace_sizes, memoised per problem shape (the per-view loop asks the same question every call)."""
     k = (prm.P, prm.K, prm.W, prm.H, prm.n_views, cap)
@@ -182,7 +175,7 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
         gsz, isz, bsz = _workspace_sizes(L, prm, cap)
         if geom is None:
             geom = torch.empty(gsz, device=dev, dtype=torch.uint8)
-        if img is None or img.numel() < isz:        # (segmented launches: the partial slots grow with the capacity)
+        if img is None or img.numel() < isz:
             img = torch.empty(isz, device=dev, dtype=torch.uint8)
         binb = torch.empty(bsz, device=dev, dtype=torch.uint8)
         args = (C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales),
@@ -273,7 +266,7 @@ def bin_sections(st: ForwardState) -> Dict[str, torch.Tensor]:
 
 def img_sections(st: ForwardState) -> Dict[str, torch.Tensor]:
     """Typed views into the image workspace of a forward: final_T [V,H,W] f32 and n_contrib [V,H,W] i32 (1-based list
-    position of the last contributor).  Behind them (segmented launches) lie the per-segment partials."""
+    position of the last contributor)."""
     V, H, W = st.prm.n_views, st.prm.H, st.prm.W
     n = V * H * W * 4
     off = (n + 255) & ~255

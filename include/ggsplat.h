@@ -285,11 +285,6 @@ int ggs_profile_read(float* ms, int n);
 const char* ggs_last_error(void);
 
 /* Library version / build target string, e.g. "ggsplat 0.1 gfx950". */
-/* Tuning / test knob: segment length of the segment-parallel compositing used by small launches (a multiple of 64;
- * 0 = off, negative = back to the default: off, or GGS_SEG=1 [GGS_SEG_LEN=n] in the environment).  Must not change
- * between a forward and its backward, nor between ggs_workspace_sizes and the calls it sizes.  Returns the previous
- * override.  No reference counterpart. */
-int ggs_set_seg_len(int len);
 const char* ggs_version(void);
 /* First 16 hex digits of the sha256 over the library's sources (csrc Makefile order): identifies the build a profile or a
  * counter collection belongs to.  No reference counterpart (the upstream extension carries no build id). */

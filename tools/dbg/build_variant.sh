@@ -1,0 +1,20 @@
+#!/bin/bash
+# build_variant.sh NAME [sed-script-file | -e 'sed expr' ...] : copy csrc to a scratch dir, apply the sed edits to ggs_render.hip
+# (or the file named by VARIANT_FILE), build, and keep the library as csrc/variants/NAME.so (A/B timing via GGS_LIB_PATH,
+# tools/dbg/ab_libs.sh).  What-if builds may compute WRONG results on purpose; they are never the product library.
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+NAME=$1; shift
+SRC=$ROOT/gaussian-garments_amd/csrc
+TMP=$(mktemp -d /tmp/ggsvar.XXXXXX)
+mkdir -p $TMP/gaussian-garments_amd/csrc $TMP/include
+cp $SRC/*.hip $SRC/*.h $SRC/Makefile $TMP/gaussian-garments_amd/csrc/
+cp $ROOT/include/*.h $TMP/include/
+F=${VARIANT_FILE:-ggs_render.hip}
+if [ $# -gt 0 ]; then sed -i "$@" $TMP/gaussian-garments_amd/csrc/$F; fi
+make -C $TMP/gaussian-garments_amd/csrc -j8 RENDER_EXTRA="$RENDER_EXTRA" > $TMP/build.log 2>&1 || { tail -30 $TMP/build.log; exit 1; }
+mkdir -p $SRC/variants
+cp $TMP/gaussian-garments_amd/csrc/libggsplat.so $SRC/variants/$NAME.so
+diff <(cat $SRC/$F) $TMP/gaussian-garments_amd/csrc/$F | head -40 || true
+rm -rf $TMP
+echo "built variants/$NAME.so"
