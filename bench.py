@@ -30,6 +30,13 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector (= f32-input MFMA) peak, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
+# Useful floating-point operations per blended (Gaussian, pixel) pair, counted from the kernels' source (an fma = 2, exp / rcp = 1):
+#   forward  (ggs_render.hip render_fwd_body): dx, dy 2 | exponent 3 mul + 2 fma 7 | exp2 1 | opacity * G 1 | min 1 | alpha * T 1 |
+#             T - w 1 | colour, depth 4 fma 8 | A += w, T -= w 2                                                      = 24
+#   backward (render_bwd_body): dx, dy 2 | exponent 7 | exp2 1 | opacity * G, min 2 | 1 - alpha, rcp 2 | T *= ra, w 2 | c . dL/dC 5 |
+#             dL/dalpha mul + fma 3 | B fma 2 | colour sums 3 fma 6 | t 1 | v_op 1 | hx, hy 2 | mx, my 2 | cx, cy, cz 3 fma 6   = 44
+FWD_FLOPS_PER_PAIR, BWD_FLOPS_PER_PAIR = 24, 44
 KERNELS = ["preprocess", "scan_tiles", "scatter", "sort_tiles", "render_fwd", "render_bwd", "preprocess_bwd", "order_tiles"]
 
 
@@ -324,6 +331,11 @@ def main():
             # blended splats per pixel (n_contrib = position of the last contributor in the tile's list)
             nc = R.img_sections(st)["n_contrib"]
             mean_contrib = float(nc.float().mean().item())
+            # (Gaussian, pixel) pairs the forward blended = the useful work of both render kernels (ggs_count_blends)
+            cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+            _lib.check(L.ggs_count_blends(C.byref(st.prm), st.geom.data_ptr(), st.bin.data_ptr(), st.cap, st.img.data_ptr(),
+                                          cnt.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "ggs_count_blends")
+            pairs_view = float(cnt.item()) / chunk
             del st
         L.ggs_profile_enable(0)
         kern_ms = {k: v / reps for k, v in zip(KERNELS, acc_ms)}
@@ -368,11 +380,26 @@ def main():
                     break
             except Exception:
                 continue
-        roofline = {"bound": "hbm", "kernel": "ggs_k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        # Compute side of the same kernel ("report both"): useful FLOP/s = blended pairs x flops per pair / kernel
+        # time, against the fp32 vector peak.  `bound` says which pipe the counters show saturated: "valu" when the committed
+        # VALUBusy of this build is above 90 % (or, without a collection, when the kernel is a compositing kernel, which
+        # every collection so far has shown VALU-saturated), else "hbm".  achieved / peak / frac stay the HBM figures the
+        # contract asks for.
+        flops_pair = {"render_fwd": FWD_FLOPS_PER_PAIR, "render_bwd": BWD_FLOPS_PER_PAIR}.get(dom)
+        compute = None
+        if flops_pair is not None:
+            tf = pairs_view * chunk * flops_pair / (group_ms[dom] * 1e-3) / 1e12
+            compute = {"useful_pairs_per_view": round(pairs_view, 1), "flops_per_pair": flops_pair,
+                       "achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS,
+                       "frac": round(tf / FP32_VECTOR_PEAK_TFLOPS, 5),
+                       "lanes_useful_pct": None if valu is None else valu["lane_activity_pct"],
+                       "note": "blended (Gaussian, pixel) pairs from ggs_count_blends; flops per pair counted from the kernel source"}
+        bound = "valu" if ((valu is not None and valu["busy_pct"] > 90.0) or (valu is None and flops_pair is not None)) else "hbm"
+        roofline = {"bound": bound, "kernel": "ggs_k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     "traffic_source": traffic_src if traffic is not None else
                     f"none: no profiles/*_hbm_traffic.json was collected from build {bid} on this workload",
-                    "valu": valu, "launch_views": chunk, "launch_ms": round(group_ms[dom], 4),
+                    "valu": valu, "compute": compute, "launch_views": chunk, "launch_ms": round(group_ms[dom], 4),
                     "alg_bytes_per_launch": int(dom_bytes),
                     "kernel_ms_per_launch": {k: round(v, 4) for k, v in kern_ms.items()},
                     # B_ref: the same lower bound with the reference algorithm's global radix sort of 64-bit
@@ -411,12 +438,23 @@ def main():
             # full s2 inner step per view: render + fused L1/SSIM loss + backward + Adam (ggsplat.inner_step)
             from ggsplat.inner_step import DEFAULT_OPT, registration_step
             model.training_setup(DEFAULT_OPT, is_ff=True)
-            gt_img = torch.rand(3, H, W, device=dev)
+            # ground truth of camera i = the INITIAL model's own render of it + a little noise: a registration that starts near its
+            # optimum, as a tracked frame does -- against a random image the Gaussians grow iteration by iteration and every
+            # later timing would measure a different (heavier) scene
+            def own_renders(mdl, sh_off=None):
+                out = []
+                with torch.no_grad():
+                    mdl.update_face_coor()
+                    for c in lcams:
+                        img = render(c, mdl, pipe, bg)["render"]
+                        out.append((img + 0.02 * torch.randn_like(img)).clamp_(0.0, 1.0).contiguous())
+                return out
+            gts = own_renders(model)
             gt_mask = (torch.rand(1, H, W, device=dev) > 0.1).float()
 
             def steps():
-                for c in lcams:
-                    registration_step(model, c, gt_img, gt_mask, bg, fused_loss=True)
+                for c, gt_i in zip(lcams, gts):
+                    registration_step(model, c, gt_i, gt_mask, bg, fused_loss=True)
             steps()
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
@@ -430,12 +468,12 @@ def main():
             from ggsplat.inner_step import GraphedRegistrationStep
             model.optimizer = GraphAdam(model.optimizer.param_groups, lr=0.0, eps=1e-15)
             gstep = GraphedRegistrationStep(model, W, H, bg)
-            for c in lcams[:2]:
-                gstep(c, gt_img, gt_mask)
+            for c, gt_i in zip(lcams[:2], gts):
+                gstep(c, gt_i, gt_mask)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
-            for c in lcams:
-                gstep(c, gt_img, gt_mask)
+            for c, gt_i in zip(lcams, gts):
+                gstep(c, gt_i, gt_mask)
             torch.cuda.synchronize(dev)
             graph_vps = len(lcams) / (time.perf_counter() - t1)
             graph_recaptures = gstep.recaptures
@@ -465,16 +503,17 @@ def main():
             o3 = GraphAdam([{"params": [net3.xyz_off], "lr": 1e-4, "name": "net_xyz"}, {"params": [net3.sh_off], "lr": 2e-3, "name": "net_sh"},
                             {"params": [m3._opacity], "lr": 1e-2, "name": "opacity"}, {"params": [m3._scaling], "lr": 2e-3, "name": "scaling"},
                             {"params": [m3._features_dc], "lr": 2.5e-3, "name": "f_dc"}], lr=0.0, eps=1e-15)
+            gts3 = own_renders(m3)
             s3step = GraphedAppearanceStep(m3, net3, W, H, bg, o3)
-            for c in lcams[:2]:
-                s3step(c, gt_img, gt_mask)
+            for c, gt_i in zip(lcams[:2], gts3):
+                s3step(c, gt_i, gt_mask)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
-            for c in lcams:
-                s3step(c, gt_img, gt_mask)
+            for c, gt_i in zip(lcams, gts3):
+                s3step(c, gt_i, gt_mask)
             torch.cuda.synchronize(dev)
             s3_vps = len(lcams) / (time.perf_counter() - t1)
-            del s3step, m3, net3, o3
+            del s3step, m3, net3, o3, gts3
 
         # ---- CPU baseline: the C oracle on the host cores, bounded sample of the same views ----
         cpu = None
@@ -540,14 +579,16 @@ def main():
                        "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
                        "ranks": ranks_seen,
                        "num_rendered_per_view": round(N_view, 1), "visible_per_view": round(P_vis, 1),
-                       "mean_list_length_per_pixel": round(N_view / T, 2),
+                       "mean_list_length_per_tile": round(N_view / T, 2),
                        "mean_last_contributor_per_pixel": round(mean_contrib, 2)},
             "roofline": roofline, "cpu_baseline": cpu,
             "build_id": bid, "library_matches_sources": bid == _lib.source_hash(), "other_configs": extras,
             "per_view_loop_views_per_sec": None if loop_vps is None else round(loop_vps, 2),
             "s2_inner_step_iters_per_sec": None if step_vps is None else round(step_vps, 2),
             "s2_graph_step_iters_per_sec": None if graph_vps is None else round(graph_vps, 2),
-            "s3_graph_step_iters_per_sec": None if s3_vps is None else round(s3_vps, 2),
+            # config-4 FORM of the s3 iteration (texel-bound Gaussians, K = 16, vis mask, five-term loss, Adam) with a two-tensor
+            # stand-in for the StyleUNet: a rasterizer + loss + optimiser number, not a config-4 number
+            "s3_graph_step_standin_net_iters_per_sec": None if s3_vps is None else round(s3_vps, 2),
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -178,6 +178,32 @@ int ggs_bin_layout(const GgsParams* p, size_t bin_capacity, size_t offsets[8]) {
     return GGS_OK;
 }
 
+int ggs_count_blends(const GgsParams* p, const void* geom, const void* bin, size_t bin_capacity, const void* img,
+                     unsigned long long* count, void* stream_) {
+    g_err[0] = 0;
+    GGS_TRY(check_params(p));
+    if (!geom || !bin || !img || !count) return fail(GGS_ERR_ARG, "ggs_count_blends: NULL pointer argument");
+    hipStream_t s = (hipStream_t)stream_;
+    if (ggs_zero_async(count, 8, s) != hipSuccess) return fail(GGS_ERR_HIP, "ggs_count_blends: clearing the counter failed");
+    if (p->P == 0) return GGS_OK;
+    const Dims d = dims(p);
+    const int V = p->n_views;
+    const BinLayout L = ggs_bin_layout(V, d.T, bin_capacity);
+    const char* b = (const char*)bin;
+    RenderBwdArgs a;
+    memset(&a, 0, sizeof(a));
+    a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.n_items = V * d.T;
+    a.tile_count = (const uint32_t*)(b + L.tile_count);
+    a.tile_offset = (const uint32_t*)(b + L.tile_offset);
+    a.view_base = (const unsigned long long*)(b + L.view_base);
+    a.ids = (const uint32_t*)(b + L.ids);
+    a.rec = (const SplatRec*)geom;
+    a.n_contrib = (const uint32_t*)((const char*)img + ggs_align((size_t)V * p->W * p->H * 4));
+    a.header = (const GgsBinHeader*)(b + L.header);
+    hipLaunchKernelGGL(ggs_k_count_blends, dim3((unsigned)a.n_items), dim3(64), 0, s, a, count);
+    return check("count_blends", s, p->debug);
+}
+
 size_t ggs_backward_scratch_bytes(const GgsParams* p) {
     if (!p || p->P < 0 || p->n_views <= 0) return 0;
     const int splits = bwd_splits(p);
@@ -269,6 +295,12 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
         ScanArgs a;
         a.T = d.T; a.capacity = (unsigned long long)bin_capacity; a.tile_count = tile_count;
         a.tile_offset = tile_offset; a.view_base = view_base; a.header = header; a.bucket_count = bucket_count;
+        if (V == 1) {             // one view: scan and work-item order in one launch (ggs_k_scan_order_one)
+            prof_start(K_SCAN, s);
+            hipLaunchKernelGGL(ggs_k_scan_order_one, dim3(1), dim3(1024), 0, s, a, order);
+            prof_stop(K_SCAN, s);
+            GGS_TRY(check("scan_order_one", s, p->debug));
+        } else {
         prof_start(K_SCAN, s);
         hipLaunchKernelGGL(ggs_k_scan_tiles, dim3((unsigned)V), dim3(1024), 0, s, a);
         prof_stop(K_SCAN, s);
@@ -280,6 +312,7 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
         hipLaunchKernelGGL(ggs_k_order_tiles, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, o);
         prof_stop(K_ORDER, s);
         GGS_TRY(check("order_tiles", s, p->debug));
+        }
     }
     }  // PHASE_COUNT
     if (!(phases & PHASE_RENDER)) { prof_collect(s); return GGS_OK; }

@@ -106,6 +106,78 @@ __global__ __launch_bounds__(256) void ggs_k_order_tiles(OrderArgs a) {
     }
 }
 
+// K2 + K2b in one launch for a SINGLE view (grid 1, block 1024): the one workgroup that scans the view's histogram already
+// holds the complete list-length class histogram in LDS, so it places the work items right away -- a single-view iteration
+// is a chain of latency-bound launches and this removes one kernel boundary and the second pass over
+// tile_count.  Same order[] layout as ggs_k_order_tiles (non-empty items longest class first at r * (k + 1), empties
+// interleaved); inside a class the order is arbitrary there and here.
+__global__ __launch_bounds__(1024) void ggs_k_scan_order_one(ScanArgs a, uint32_t* order) {
+    const int tid = threadIdx.x;
+    const uint32_t* cnt = a.tile_count;
+    uint32_t* off = a.tile_offset;
+    const int per = (a.T + 1023) / 1024;
+    const int t0 = tid * per;
+    __shared__ uint32_t s_bucket[GGS_NBUCKET], s_start[GGS_NBUCKET], s_cur[GGS_NBUCKET];
+    __shared__ uint32_t wsum[16], wemp[16];
+    if (tid < GGS_NBUCKET) { s_bucket[tid] = 0; s_cur[tid] = 0; }
+    __syncthreads();
+    uint32_t local = 0, n_empty = 0;
+    for (int i = 0; i < per; ++i)
+        if (t0 + i < a.T) {
+            const uint32_t c = cnt[t0 + i];
+            local += c;
+            if (c == 0) ++n_empty;
+            else atomicAdd(&s_bucket[ggs_len_bucket(c)], 1u);
+        }
+    // inclusive scans (list entries, empty tiles) inside each wave64, then across the 16 waves
+    const int lane = tid & 63, wave = tid >> 6;
+    uint32_t x = local, e = n_empty;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t y = __shfl_up(x, d), z = __shfl_up(e, d);
+        if (lane >= d) { x += y; e += z; }
+    }
+    if (lane == 63) { wsum[wave] = x; wemp[wave] = e; }
+    __syncthreads();
+    uint32_t wbase = 0, total = 0, ebase = 0, E = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        if (w < wave) { wbase += wsum[w]; ebase += wemp[w]; }
+        total += wsum[w]; E += wemp[w];
+    }
+    if (tid < GGS_NBUCKET) {
+        uint32_t start = 0;
+        for (int k = 0; k < tid; ++k) start += s_bucket[k];
+        s_start[tid] = start;
+        const uint32_t n = tid == GGS_NBUCKET - 1 ? E : s_bucket[tid];
+        if (n) atomicAdd(&a.bucket_count[tid], n);
+    }
+    __syncthreads();
+    const uint32_t NE = (uint32_t)a.T - E;
+    const uint32_t k = NE ? (E / NE) & ~1u : 0;            // even: see ggs_k_order_tiles
+    uint32_t run = wbase + x - local, er = ebase + e - n_empty;
+    for (int i = 0; i < per; ++i)
+        if (t0 + i < a.T) {
+            const uint32_t c = cnt[t0 + i];
+            off[t0 + i] = run;
+            run += c;
+            uint32_t pos;
+            if (c) {
+                const int b = ggs_len_bucket(c);
+                pos = (s_start[b] + atomicAdd(&s_cur[b], 1u)) * (k + 1);
+            } else {
+                const uint32_t r = er++;
+                pos = r < k * NE ? (r / k) * (k + 1) + 1 + (r % k) : NE * (k + 1) + (r - k * NE);
+            }
+            order[pos] = (uint32_t)(t0 + i);
+        }
+    if (tid == 0) {
+        const unsigned long long base = atomicAdd(&a.header->num_rendered, (unsigned long long)total);
+        a.view_base[0] = base;
+        if (base + total > a.capacity) atomicExch(&a.header->overflow, 1ull);
+    }
+}
+
 namespace {
 
 // sort order = (depth bits, Gaussian id): the key is depth << 32 | id << 4 | quadrant mask, so the plain 64-bit

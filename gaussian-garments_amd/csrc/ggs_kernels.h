@@ -106,6 +106,7 @@ __global__ void ggs_k_preprocess(PreArgs a);
 __global__ void ggs_k_scan_tiles(ScanArgs a);
 __global__ void ggs_k_scatter(ScatterArgs a);
 __global__ void ggs_k_order_tiles(OrderArgs a);
+__global__ void ggs_k_scan_order_one(ScanArgs a, uint32_t* order);
 __global__ void ggs_k_sort_tiles(SortArgs a, unsigned n_block);
 __global__ void ggs_k_sort_tiles_wave(SortArgs a);
 __global__ void ggs_k_render_fwd(RenderArgs a);
@@ -114,6 +115,7 @@ __global__ void ggs_k_render_bwd(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_da(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_quad(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_da_quad(RenderBwdArgs a);
+__global__ void ggs_k_count_blends(RenderBwdArgs a, unsigned long long* out);
 __global__ void ggs_k_preprocess_bwd_sh0(PreBwdArgs a);
 __global__ void ggs_k_preprocess_bwd_sh1(PreBwdArgs a);
 __global__ void ggs_k_preprocess_bwd_sh2(PreBwdArgs a);

@@ -33,6 +33,8 @@ __device__ __constant__ const float G11[11] = {1.028380124e-03f, 7.598758209e-03
 struct LossArgs {
     int V, H, W;
     const float *img, *gt, *mask;     // [V][3][H][W], [V][3][H][W], [V][1][H][W] or null
+    const float* const* gt_tab;       // table form: device array of V device pointers to [3][H][W] images (gt is null then)
+    const float* const* mask_tab;     //             device array of V device pointers to [H][W] masks, or null
     const float* w;                   // [V][2] device: weights of mean|x-y| and of mean ssim_map in the loss
     float inv_n;                      // 1 / (3 H W)
     float* sums;                      // [V][2] = {sum |x - y|, sum ssim_map}
@@ -66,7 +68,10 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
 // stores are issued BEFORE the loads that the next step waits for: vmcnt retires in order, so a store issued after
 // them would put its whole write latency on the critical path of every step.
 #define LS_COLS 64
-#define LS_HB 34                          // LS_HB + 2 LH = 44 input rows = 4 x 11
+#define LS_HB 34                          // LS_HB + 2 LH = 44 input rows = 4 x 11.  (12-row bands for single-view launches --
+                                          // 2.8x the waves, half the dependent row steps each, 1.8x the filtered rows --
+                                          // measured 0.166 against 0.104 ms per 1080p view: the pass is bound by its VALU
+                                          // work per row, not by the latency of a row step.)
 #define LS_IN (LS_COLS + 2 * LH)          // 74
 #define LS_WAVES 4                        // waves per workgroup: consecutive bands of one strip
 
@@ -196,8 +201,9 @@ __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float 
     const int band = blockIdx.y * LS_WAVES + wave;
     const size_t HW = (size_t)a.H * a.W;
     StatsCtx c;
-    c.img = a.img + ((size_t)v * 3 + ch) * HW; c.gt = a.gt + ((size_t)v * 3 + ch) * HW;
-    c.mask = MASK ? a.mask + (size_t)v * HW : nullptr;
+    c.img = a.img + ((size_t)v * 3 + ch) * HW;
+    c.gt = a.gt_tab ? a.gt_tab[v] + (size_t)ch * HW : a.gt + ((size_t)v * 3 + ch) * HW;
+    c.mask = !MASK ? nullptr : a.mask_tab ? a.mask_tab[v] : a.mask + (size_t)v * HW;
     c.dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW;
     c.H = a.H; c.W = a.W; c.oy = band * LS_HB; c.ox = blockIdx.x * LS_COLS; c.lane = lane; c.HW = HW;
     c.sx = s_x[wave]; c.sy = s_y[wave];
@@ -225,11 +231,17 @@ __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float 
 }  // namespace
 
 // Pass A: grid (ceil(W/64), ceil(ceil(H/34)/4), V*3), block 256 = 4 independent waves.
+// (Masked and unmasked forms are separate kernels: as two branches of one kernel the register allocation of the shared
+// prologue pushed the masked body over its 128 VGPRs -- 8 spilled registers, 32 B of scratch per lane.)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ggs_k_loss_stats(LossArgs a) {
     __shared__ float s_x[LS_WAVES][2][LS_IN], s_y[LS_WAVES][2][LS_IN];
     __shared__ float s_red[4];
-    if (a.mask) loss_stats_stream_body<true>(a, s_x, s_y, s_red);
-    else loss_stats_stream_body<false>(a, s_x, s_y, s_red);
+    loss_stats_stream_body<false>(a, s_x, s_y, s_red);
+}
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ggs_k_loss_stats_masked(LossArgs a) {
+    __shared__ float s_x[LS_WAVES][2][LS_IN], s_y[LS_WAVES][2][LS_IN];
+    __shared__ float s_red[4];
+    loss_stats_stream_body<true>(a, s_x, s_y, s_red);
 }
 
 namespace {
@@ -313,8 +325,9 @@ __device__ __forceinline__ void loss_grad_stream_body(const LossArgs& a, float (
     const int band = blockIdx.y * LS_WAVES + wave;
     const size_t HW = (size_t)a.H * a.W;
     GradCtx c;
-    c.img = a.img + ((size_t)v * 3 + ch) * HW; c.gt = a.gt + ((size_t)v * 3 + ch) * HW;
-    c.mask = MASK ? a.mask + (size_t)v * HW : nullptr;
+    c.img = a.img + ((size_t)v * 3 + ch) * HW;
+    c.gt = a.gt_tab ? a.gt_tab[v] + (size_t)ch * HW : a.gt + ((size_t)v * 3 + ch) * HW;
+    c.mask = !MASK ? nullptr : a.mask_tab ? a.mask_tab[v] : a.mask + (size_t)v * HW;
     c.dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW;
     c.out = a.dL_dimg + ((size_t)v * 3 + ch) * HW;
     c.H = a.H; c.W = a.W; c.oy = band * LS_HB; c.ox = blockIdx.x * LS_COLS; c.lane = lane; c.HW = HW;
@@ -337,7 +350,7 @@ __device__ __forceinline__ void loss_grad_stream_body(const LossArgs& a, float (
 // Pass B: same decomposition as pass A.
 __global__ __launch_bounds__(256) void ggs_k_loss_grad(LossArgs a) {
     __shared__ float s_d[LS_WAVES][2][3][LS_IN];
-    if (a.mask) loss_grad_stream_body<true>(a, s_d);
+    if (a.mask || a.mask_tab) loss_grad_stream_body<true>(a, s_d);
     else loss_grad_stream_body<false>(a, s_d);
 }
 
@@ -349,21 +362,22 @@ size_t ggs_photometric_scratch_bytes(int n_views, int H, int W) {
 }
 
 static int loss_args(LossArgs& a, int n_views, int H, int W, const float* img, const float* gt, const float* mask,
-                     void* scratch, const char* who) {
+                     const float* const* gt_tab, const float* const* mask_tab, void* scratch, const char* who) {
     ggs_clear_error_();
     if (n_views <= 0 || H <= 0 || W <= 0) return ggs_fail_(GGS_ERR_ARG, "%s: bad sizes", who);
-    if (!img || !gt || !scratch) return ggs_fail_(GGS_ERR_ARG, "%s: NULL pointer argument", who);
+    if (!img || !(gt || gt_tab) || !scratch) return ggs_fail_(GGS_ERR_ARG, "%s: NULL pointer argument", who);
     if ((size_t)n_views * 3 > 65535) return ggs_fail_(GGS_ERR_SIZE, "%s: n_views too large", who);
-    a.V = n_views; a.H = H; a.W = W; a.img = img; a.gt = gt; a.mask = mask;
+    a.V = n_views; a.H = H; a.W = W; a.img = img; a.gt = gt; a.mask = mask; a.gt_tab = gt_tab; a.mask_tab = mask_tab;
     a.inv_n = 1.f / (3.f * (float)H * (float)W);
     a.w = nullptr; a.sums = nullptr; a.dL_dimg = nullptr; a.dmap = (float*)scratch;
     return GGS_OK;
 }
 
-int ggs_photometric_forward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
-                            float* sums, void* scratch, void* stream_) {
+static int photometric_forward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
+                               const float* const* gt_tab, const float* const* mask_tab, float* sums, void* scratch,
+                               void* stream_) {
     LossArgs a;
-    int rc = loss_args(a, n_views, H, W, img, gt, mask, scratch, "ggs_photometric_forward");
+    int rc = loss_args(a, n_views, H, W, img, gt, mask, gt_tab, mask_tab, scratch, "ggs_photometric_forward");
     if (rc != GGS_OK) return rc;
     if (!sums) return ggs_fail_(GGS_ERR_ARG, "ggs_photometric_forward: sums is NULL");
     hipStream_t s = (hipStream_t)stream_;
@@ -372,16 +386,18 @@ int ggs_photometric_forward(int n_views, int H, int W, const float* img, const f
         return ggs_fail_(GGS_ERR_HIP, "ggs_photometric_forward: clearing the sums failed");
     const int bands = (H + LS_HB - 1) / LS_HB;
     const dim3 grid((unsigned)((W + LS_COLS - 1) / LS_COLS), (unsigned)((bands + LS_WAVES - 1) / LS_WAVES), (unsigned)(n_views * 3));
-    hipLaunchKernelGGL(ggs_k_loss_stats, grid, dim3(256), 0, s, a);
+    if (a.mask || a.mask_tab) hipLaunchKernelGGL(ggs_k_loss_stats_masked, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(ggs_k_loss_stats, grid, dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "loss_stats launch failed: %s", hipGetErrorString(e));
     return GGS_OK;
 }
 
-int ggs_photometric_backward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
-                             const void* scratch, const float* weights, float* dL_dimg, void* stream_) {
+static int photometric_backward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
+                                const float* const* gt_tab, const float* const* mask_tab, const void* scratch,
+                                const float* weights, float* dL_dimg, void* stream_) {
     LossArgs a;
-    int rc = loss_args(a, n_views, H, W, img, gt, mask, (void*)scratch, "ggs_photometric_backward");
+    int rc = loss_args(a, n_views, H, W, img, gt, mask, gt_tab, mask_tab, (void*)scratch, "ggs_photometric_backward");
     if (rc != GGS_OK) return rc;
     if (!weights || !dL_dimg) return ggs_fail_(GGS_ERR_ARG, "ggs_photometric_backward: NULL pointer argument");
     a.w = weights; a.dL_dimg = dL_dimg;
@@ -391,6 +407,27 @@ int ggs_photometric_backward(int n_views, int H, int W, const float* img, const 
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "loss_grad launch failed: %s", hipGetErrorString(e));
     return GGS_OK;
+}
+
+int ggs_photometric_forward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
+                            float* sums, void* scratch, void* stream) {
+    return photometric_forward(n_views, H, W, img, gt, mask, nullptr, nullptr, sums, scratch, stream);
+}
+int ggs_photometric_backward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
+                             const void* scratch, const float* weights, float* dL_dimg, void* stream) {
+    return photometric_backward(n_views, H, W, img, gt, mask, nullptr, nullptr, scratch, weights, dL_dimg, stream);
+}
+// Table form: the ground-truth images (and masks) are named by DEVICE-resident pointer tables that the kernels read at run
+// time, so a captured hipGraph can be replayed on another camera's images by rewriting 8 bytes per image instead of copying
+// 33 MB into static buffers.
+int ggs_photometric_forward_tab(int n_views, int H, int W, const float* img, const float* const* gt_tab,
+                                const float* const* mask_tab, float* sums, void* scratch, void* stream) {
+    return photometric_forward(n_views, H, W, img, nullptr, nullptr, gt_tab, mask_tab, sums, scratch, stream);
+}
+int ggs_photometric_backward_tab(int n_views, int H, int W, const float* img, const float* const* gt_tab,
+                                 const float* const* mask_tab, const void* scratch, const float* weights, float* dL_dimg,
+                                 void* stream) {
+    return photometric_backward(n_views, H, W, img, nullptr, nullptr, gt_tab, mask_tab, scratch, weights, dL_dimg, stream);
 }
 
 }  // extern "C"

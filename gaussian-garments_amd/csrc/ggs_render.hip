@@ -502,3 +502,53 @@ __global__ __launch_bounds__(64) void ggs_k_render_bwd(RenderBwdArgs a) { render
 __global__ __launch_bounds__(64) void ggs_k_render_bwd_da(RenderBwdArgs a) { render_bwd_body<true, 4>(a); }
 __global__ __launch_bounds__(64) void ggs_k_render_bwd_quad(RenderBwdArgs a) { render_bwd_body<false, 1>(a); }
 __global__ __launch_bounds__(64) void ggs_k_render_bwd_da_quad(RenderBwdArgs a) { render_bwd_body<true, 1>(a); }
+
+// Introspection (bench.py's compute-side roofline): the number of (splat, pixel) pairs the forward BLENDED, i.e. the pairs
+// the backward differentiates -- list position below the pixel's last contributor, falloff exponent <= 0, alpha >= 1/255 --
+// counted with the backward's own tests over the forward's lists.  One wave per work item; not on any timed path.
+__global__ __launch_bounds__(64) void ggs_k_count_blends(RenderBwdArgs a, unsigned long long* out) {
+    if (a.header->overflow) return;
+    const uint32_t item = blockIdx.x;
+    const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
+    const int L = (int)a.tile_count[(size_t)v * a.T + t];
+    if (L == 0) return;
+    const int tx = t % a.gx, ty = t / a.gx;
+    const int px0 = tx * GGS_TILE + (lane & 7), py0 = ty * GGS_TILE + (lane >> 3);
+    const size_t HW = (size_t)a.H * a.W;
+    const uint32_t* __restrict__ ids = a.ids + (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
+    const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
+    float pxf[4], pyf[4];
+    int nc[4], maxc = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
+        pxf[q] = (float)px; pyf[q] = (float)py;
+        nc[q] = px < a.W && py < a.H ? (int)a.n_contrib[(size_t)v * HW + (size_t)py * a.W + px] : 0;
+        maxc = max(maxc, nc[q]);
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
+    maxc = __builtin_amdgcn_readfirstlane(maxc);
+    __shared__ float4 s_rec[64 * 3];
+    RoundLds lds{s_rec};
+    unsigned long long n = 0;
+    for (int first = 0; first < maxc; first += 64) {
+        const Rec3 cur = gather_round(rec, ids, first, L, lane);
+        lds.put(cur, lane);
+        const int cnt = min(64, maxc - first);
+        for (int j = 0; j < cnt; ++j) {
+            const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, j);
+            const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (!(word & (1u << (GGS_ID_BITS + q)))) continue;
+                const float dx = ra.x - pxf[q], dy = ra.y - pyf[q];
+                const float power = fmaf(ra.z * dx, dx, fmaf(rb.x * dy, dy, (ra.w * dx) * dy));
+                const float ar = __builtin_fminf(GGS_ALPHA_MAX, rb.y * __builtin_amdgcn_exp2f(power));
+                n += __popcll(__builtin_amdgcn_ballot_w64((first + j < nc[q]) & (power <= 0.f) & (ar >= GGS_ALPHA_MIN)));
+            }
+        }
+    }
+    if (lane == 0 && n) atomicAdd(out, n);
+}
+

@@ -43,6 +43,8 @@ _SIGS = {
     "ggs_photometric_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "ggs_photometric_forward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 6),
     "ggs_photometric_backward": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 7),
+    "ggs_photometric_forward_tab": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 6),
+    "ggs_photometric_backward_tab": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 7),
     "ggs_dist2_3nn": (C.c_int, [C.c_int, _PTR, _PTR, _PTR]),
     "ggs_fused_bias_act": (C.c_int, [C.c_size_t, _PTR, _PTR, _PTR, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _PTR, _PTR]),
     "ggs_fused_bias_act_t": (C.c_int, [C.c_int, C.c_size_t, _PTR, _PTR, _PTR, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _PTR, _PTR]),
@@ -57,6 +59,7 @@ _SIGS = {
     "ggs_registration_aux": (C.c_int, [C.c_int] + [_PTR] * 7 + [C.c_float] * 4 + [_PTR] * 9),
     "ggs_visibility_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_size_t]),
     "ggs_visibility": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 6 + [C.c_size_t, _PTR, _PTR, _PTR]),
+    "ggs_count_blends": (C.c_int, [C.POINTER(GgsParams), _PTR, _PTR, C.c_size_t, _PTR, _PTR, _PTR]),
     "ggs_profile_enable": (C.c_int, [C.c_int]),
     "ggs_profile_read": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
     "ggs_last_error": (C.c_char_p, []),

@@ -114,8 +114,10 @@ class GraphedRegistrationStep:
     densification stats -> Adam) captured ONCE into a hipGraph and replayed per iteration.
 
     The reference's loop is launch- and sync-bound on a fast GPU: ~60 small kernels and several host round trips
-    per iteration for ~1 ms of GPU work.  A replay is one graph launch; camera, ground truth and mask are copied
-    into static buffers in front of it; the learning rates live on the device (GraphAdam.push_lr).  The rasterizer
+    per iteration for ~1 ms of GPU work.  A replay is one graph launch behind ONE 176-byte H2D copy (camera matrices,
+    tangents and the device addresses of this iteration's ground truth / mask, which the loss kernels read through a
+    pointer table -- images already on the GPU are not copied) and in front of ONE 48-byte read-back (loss statistics +
+    the rasterizer's overflow word); the learning rates live on the device (GraphAdam.push_lr).  The rasterizer
     runs with the binning capacity learnt during the eager warm-up; if a replayed step overflows it, the guarded
     kernels leave parameters, moments and statistics untouched, and this class grows the capacity, re-captures and
     replays the step -- so results never depend on the capacity guess.
@@ -137,19 +139,31 @@ class GraphedRegistrationStep:
         dev = gaussians._xyz.device
         self.g, self.opt, self.pipe, self.bg = gaussians, opt, pipe, bg
         self.fft, self.track = first_frame_template, track_densification
+        # Everything that changes from one iteration to the next sits in ONE 176-byte device block, refreshed by one H2D copy
+        # from a pinned staging block: view [16] | full projection [16] | camera centre [3] | tan(fov/2) [2] | pad [3] floats,
+        # then two device pointers (ground truth, mask) that the loss kernels read through (ggs_photometric_*_tab).
+        self._blk = torch.zeros(176, dtype=torch.uint8, device=dev)
+        self._blk_host = torch.zeros(176, dtype=torch.uint8).pin_memory()
+        f = self._blk[:160].view(torch.float32)
         self.cam = SimpleNamespace(
-            image_height=H, image_width=W, world_view_transform=torch.zeros(4, 4, device=dev),
-            full_proj_transform=torch.zeros(4, 4, device=dev), camera_center=torch.zeros(3, device=dev),
-            tanfov=torch.zeros(1, 2, device=dev))
-        self.gt = torch.zeros(3, H, W, device=dev)
+            image_height=H, image_width=W, world_view_transform=f[0:16].view(4, 4), full_proj_transform=f[16:32].view(4, 4),
+            camera_center=f[32:35], tanfov=f[35:37].view(1, 2))
+        self._ptrs = self._blk[160:176].view(torch.int64)
+        self._host_f = self._blk_host[:160].view(torch.float32)
+        self._host_p = self._blk_host[160:176].view(torch.int64)
+        self._cam_cache: Dict[int, tuple] = {}
+        self._keep = None                                   # the tensors the pointer table names, alive until the replay is done
+        self.gt = torch.zeros(3, H, W, device=dev)          # landing buffers for images that arrive on the host
         self.mask = torch.ones(1, H, W, device=dev) if use_mask else None
-        self._tan_host = torch.zeros(1, 2).pin_memory()
-        self._hdr_host = torch.zeros(2, dtype=torch.int64).pin_memory()
+        # what the host reads back per iteration, in one D2H copy: 8 floats of loss statistics + the bin header (2 x int64)
+        self._out = torch.zeros(48, dtype=torch.uint8, device=dev)
+        self._out_host = torch.zeros(48, dtype=torch.uint8).pin_memory()
+        self._hdr_host = self._out_host[32:48].view(torch.int64)
         self.lean = bool(lean)
         lam = float(opt.lambda_dssim)
         self._w = torch.tensor([[1.0 - lam, -lam]], device=dev)          # d loss / d {mean|x-y|, mean ssim}
-        self._stats = torch.zeros(8, device=dev)                          # {sum|x-y|, sum ssim, loss_xyz, loss_scale, n_vis}
-        self._stats_host = torch.zeros(8).pin_memory()
+        self._stats = self._out[:32].view(torch.float32)                  # {sum|x-y|, sum ssim, loss_xyz, loss_scale, n_vis}
+        self._stats_host = self._out_host[:32].view(torch.float32)
         self._aux_scratch = torch.zeros(4, device=dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out: Dict[str, torch.Tensor] = {}
@@ -157,17 +171,44 @@ class GraphedRegistrationStep:
         self.optimizer = gaussians.optimizer
         self._slack = float(capacity_slack)     # applied once to the learnt capacity (< 1 exercises the recovery path)
 
-    def _load(self, cam, gt_image, mask):
+    def _packed_camera(self, cam) -> torch.Tensor:
+        """The 37 floats of a camera (matrices, centre, tangents) as a host tensor, packed once per camera object (the
+        reference's Camera keeps its matrices on the GPU, scene/cameras.py:59-62: one read-back each, at first use)."""
         import math
-        c = self.cam
-        c.world_view_transform.copy_(cam.world_view_transform, non_blocking=True)
-        c.full_proj_transform.copy_(cam.full_proj_transform, non_blocking=True)
-        c.camera_center.copy_(cam.camera_center, non_blocking=True)
-        self._tan_host[0, 0], self._tan_host[0, 1] = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
-        c.tanfov.copy_(self._tan_host, non_blocking=True)
-        self.gt.copy_(gt_image, non_blocking=True)
-        if self.mask is not None and mask is not None:
-            self.mask.copy_(mask.reshape(self.mask.shape), non_blocking=True)
+        ent = self._cam_cache.get(id(cam))
+        if ent is not None and ent[0] is cam:
+            return ent[1]
+        t = torch.zeros(40)
+        t[0:16] = cam.world_view_transform.detach().reshape(16).float().cpu()
+        t[16:32] = cam.full_proj_transform.detach().reshape(16).float().cpu()
+        t[32:35] = cam.camera_center.detach().reshape(3).float().cpu()
+        t[35], t[36] = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
+        if len(self._cam_cache) > 4096:
+            self._cam_cache.clear()
+        self._cam_cache[id(cam)] = (cam, t)
+        return t
+
+    def _resident(self, t, landing, shape):
+        """A contiguous fp32 device tensor holding `t`: `t` itself when it already is one (no copy), else the landing buffer."""
+        if t.device == landing.device and t.dtype is torch.float32 and t.is_contiguous() and t.numel() == landing.numel():
+            return t
+        landing.copy_(t.reshape(shape), non_blocking=True)
+        return landing
+
+    def _load(self, cam, gt_image, mask):
+        self._host_f[:40] = self._packed_camera(cam)
+        gt = self._resident(gt_image, self.gt, self.gt.shape)
+        m = None
+        if self.mask is not None:
+            m = self.mask if mask is None else self._resident(mask, self.mask, self.mask.shape)
+        self._keep = (gt, m)
+        self._host_p[0], self._host_p[1] = gt.data_ptr(), (m.data_ptr() if m is not None else 0)
+        self._blk.copy_(self._blk_host, non_blocking=True)
+        if not self.lean:           # the autograd form reads the images from the static buffers
+            if gt is not self.gt:
+                self.gt.copy_(gt, non_blocking=True)
+            if m is not None and m is not self.mask:
+                self.mask.copy_(m, non_blocking=True)
 
     def _body_lean(self, optimizer_step: bool, track: bool):
         """registration_step() without autograd: the same kernels in the same order, called through the C ABI."""
@@ -193,13 +234,14 @@ class GraphedRegistrationStep:
                 proj=cam.full_proj_transform, campos=cam.camera_center, tanfov=cam.tanfov, bg=self.bg, W=W, H=H,
                 sh_degree=g.active_sh_degree, debug=self.pipe.debug)
             hdr = R.last_header()
-            m = self.mask if opt.only_foreground_loss else None
+            use_m = self.mask is not None and opt.only_foreground_loss
+            gt_tab, m_tab = self._ptrs[0:1], (self._ptrs[1:2] if use_m else None)
             scratch = torch.empty(L.ggs_photometric_scratch_bytes(1, H, W), device=dev, dtype=torch.uint8)
-            check(L.ggs_photometric_forward(1, H, W, ptr(color), ptr(self.gt), ptr(m), ptr(self._stats[0:2]),
-                                            ptr(scratch), stream), "ggs_photometric_forward")
+            check(L.ggs_photometric_forward_tab(1, H, W, ptr(color), ptr(gt_tab), ptr(m_tab), ptr(self._stats[0:2]),
+                                                ptr(scratch), stream), "ggs_photometric_forward_tab")
             dimg = torch.empty_like(color)
-            check(L.ggs_photometric_backward(1, H, W, ptr(color), ptr(self.gt), ptr(m), ptr(scratch), ptr(self._w),
-                                             ptr(dimg), stream), "ggs_photometric_backward")
+            check(L.ggs_photometric_backward_tab(1, H, W, ptr(color), ptr(gt_tab), ptr(m_tab), ptr(scratch), ptr(self._w),
+                                                 ptr(dimg), stream), "ggs_photometric_backward_tab")
             gr = R.backward_views(st, dimg, want_means2D=True)
             d_verts = torch.zeros_like(verts)
             d_xyz, d_ls, d_rr = torch.empty_like(g._xyz), torch.empty_like(g._scaling), torch.empty_like(g._rotation)
@@ -266,6 +308,7 @@ class GraphedRegistrationStep:
             warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")   # capture stream
             out = self._body(optimizer_step=True, track=self.track)
             self._hdr_dev = R.last_header()
+            torch.add(self._hdr_dev, 0, out=self._out[32:48].view(torch.int64))   # next to the statistics: one read-back
         self.out = {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
 
     def __call__(self, cam, gt_image, mask=None) -> Dict[str, torch.Tensor]:
@@ -277,10 +320,9 @@ class GraphedRegistrationStep:
             # the capture itself does not execute anything: fall through to the first replay
         while True:
             self.graph.replay()
-            self._hdr_host.copy_(self._hdr_dev, non_blocking=True)
-            if self.lean:
-                self._stats_host.copy_(self._stats, non_blocking=True)
+            self._out_host.copy_(self._out, non_blocking=True)
             torch.cuda.current_stream().synchronize()
+            self._keep = None
             if int(self._hdr_host[1]) == 0:
                 return self._losses_from_stats() if self.lean else self.out
             # the static binning capacity was too small for this view: nothing was updated (guarded kernels)

@@ -91,6 +91,17 @@ def visible_mask(verts, faces, binding, targets, camera, return_first_hit: bool 
     return (mask.bool(), first) if return_first_hit else mask.bool()
 
 
+def _version_of(t):
+    """Autograd version counter of a tensor (None for a missing input; inference-mode tensors have none and cannot be
+    modified in place outside inference mode: a constant stands in)."""
+    if t is None:
+        return None
+    try:
+        return t._version
+    except RuntimeError:
+        return -1
+
+
 class MeshGaussianModel:
     def __init__(self, sh_degree: int):
         self.active_sh_degree = 0
@@ -145,15 +156,18 @@ class MeshGaussianModel:
         graph and must not be handed to a later render() that needs gradients."""
         local = self.local_xyz if final else self._xyz
         ins = (self.mesh.v, local, self._scaling, self._rotation, self.gs_bc, self.mesh.f, self.binding)
-        return (final, torch.is_grad_enabled()) + tuple((id(t), t._version) if t is not None else None for t in ins)
+        return (final, torch.is_grad_enabled()), ins, tuple(_version_of(t) for t in ins)
 
     def _bind(self, final: bool = False):
-        key = self._bind_key(final)
-        if self._bound is None or self._bound[0] != key:
+        mode, ins, vers = self._bind_key(final)
+        b = self._bound
+        # the cache entry keeps REFERENCES to its inputs and compares them with `is`: a freshly assigned tensor (the
+        # per-frame LBS path replaces mesh.v) can reuse the id() of a dead one, a live reference cannot be reused
+        if b is None or b[0] != mode or b[2] != vers or len(b[1]) != len(ins) or any(x is not y for x, y in zip(b[1], ins)):
             local = self.local_xyz if final else self._xyz
-            self._bound = (key, mesh_bind(self.mesh.v, self.mesh.f, self.binding, local, self._scaling,
-                                          self._rotation, self.gs_bc))
-        return self._bound[1]
+            self._bound = b = (mode, ins, vers, mesh_bind(self.mesh.v, self.mesh.f, self.binding, local, self._scaling,
+                                                            self._rotation, self.gs_bc))
+        return b[3]
 
     def _bound_final(self) -> bool:
         return self._bound is not None and self._bound[0][0] and self.local_xyz is not None

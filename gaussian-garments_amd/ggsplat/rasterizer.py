@@ -26,13 +26,13 @@ from ._lib import GgsParams, check, lib, ptr
 
 # running estimate of the binning capacity per (device, P, W, H, V); grows on overflow
 _cap_hint: Dict[Tuple, int] = {}
-# bin header {num_rendered, overflow} (device int64[2]) of the most recent forward_views call
-_last_header: Optional[torch.Tensor] = None
 
 
 def last_header() -> Optional[torch.Tensor]:
-    """Device int64[2] = GgsBinHeader {num_rendered, overflow} of the most recent forward (aliases its workspace)."""
-    return _last_header
+    """Device int64[2] = GgsBinHeader {num_rendered, overflow} of the most recent forward ISSUED BY THE CALLING THREAD
+    (aliases its workspace).  Per thread, like the pinned landing buffer: the guarded optimiser step of one thread must
+    not read the overflow word of a forward that another thread (an eval worker) issued in between."""
+    return getattr(_pinned, "last_header", None)
 
 
 # headers of the forwards issued while a stream was being captured (the graph owner checks their overflow words)
@@ -92,6 +92,17 @@ def _pinned_header(dev) -> torch.Tensor:
     return t
 
 
+def _header_event(dev) -> "torch.cuda.Event":
+    """Event marking the header copy of a forward, one per (thread, device)."""
+    d = getattr(_pinned, "ev", None)
+    if d is None:
+        d = _pinned.ev = {}
+    e = d.get(dev.index)
+    if e is None:
+        e = d[dev.index] = torch.cuda.Event()
+    return e
+
+
 def tanfov_tensor(tanfovx: float, tanfovy: float, dev) -> torch.Tensor:
     """[1,2] device tensor of the two tangents, cached per camera intrinsics (avoids an H2D copy per call)."""
     k = (float(tanfovx), float(tanfovy), dev.index)
@@ -149,7 +160,6 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
     alpha = torch.empty(V, H, W, device=dev, dtype=torch.float32)
     radii = torch.empty(V, P, device=dev, dtype=torch.int32)
 
-    global _last_header
     key = (dev.index, P, W, H, V)
     cap = _cap_hint.get(key, max(8 * P * V, 1 << 16))
     cur_stream = torch.cuda.current_stream(dev)
@@ -181,20 +191,25 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
         args = (C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales),
                 ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov), ptr(geom),
                 ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha), ptr(radii), stream)
-        # phase 1: preprocess + tile histogram + scan.  The ONLY host sync of the call waits for these ~10 us
-        # of GPU work (the upstream extension syncs at the same point to size its binning buffer).
+        # phase 1: preprocess + tile histogram + scan; its 16-byte header {num_rendered, overflow} is copied out behind it.
+        # phase 2 (scatter + sort + composite) is queued right away, WITHOUT waiting for the header: every kernel of it is
+        # guarded by the overflow word on the device, so with the capacity learnt from earlier calls it is simply the
+        # render, and in the rare overflow case it composites nothing and the call is repeated with the exact size.  The
+        # ONLY host sync of the call waits for the header copy (~10 us of GPU work in front of it -- the same point where
+        # the upstream extension syncs to size its binning buffer) while the GPU is already compositing.
         check(L.ggs_forward_count(*args), "ggs_forward_count")
         host.copy_(binb[:16].view(torch.int64), non_blocking=True)
-        cur_stream.synchronize()
+        ev = _header_event(dev)
+        ev.record(cur_stream)
+        check(L.ggs_forward_render(*args), "ggs_forward_render")
+        ev.synchronize()
         n, overflow = int(host[0]), int(host[1])
         if not overflow:
             break
         cap = int(n * 1.25) + 1024             # n is exact: one retry is always enough
     if not capturing:
         _cap_hint[key] = max(cap if n * 2 <= cap else int(n * 2), 1 << 16)
-        # phase 2: scatter + sort + composite, queued without waiting
-        check(L.ggs_forward_render(*args), "ggs_forward_render")
-    _last_header = binb[:16].view(torch.int64)
+    _last_header = _pinned.last_header = binb[:16].view(torch.int64)
     if capturing:
         _capture_headers.append(_last_header)
     st = None
@@ -294,8 +309,10 @@ class _RasterizeGaussians(torch.autograd.Function):
         # forward and backward would silently change the gradients.  save_for_backward would also hold the outputs'
         # graph alive for callers that mutate them; recording the version counters gives the same protection: the
         # upstream extension raises autograd's "modified by an inplace operation" error in that situation, so do we.
+        # (Only the tensors the native backward re-reads; `opacities` is not among them -- the backward takes the opacity
+        # from the forward's records -- and upstream does not save it either.)
         ctx.in_versions = [(n, t, t._version) for n, t in (("means3D", means3D), ("sh", sh), ("colors_precomp", colors_precomp),
-                                                            ("opacities", opacities), ("scales", scales), ("rotations", rotations),
+                                                            ("scales", scales), ("rotations", rotations),
                                                             ("cov3Ds_precomp", cov3Ds_precomp)) if t is not None]
         ctx.m2d_shape = means2D.shape
         # Outputs are never saved: callers mutate them in place (ssim does `img1 *= mask`,

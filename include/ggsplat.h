@@ -180,6 +180,16 @@ int ggs_photometric_forward(int n_views, int H, int W, const float* img, const f
                             float* sums, void* scratch, void* stream);
 int ggs_photometric_backward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
                              const void* scratch, const float* weights, float* dL_dimg, void* stream);
+/* Table form of the two calls above: `gt_tab` / `mask_tab` are DEVICE arrays of n_views device pointers (to one [3][H][W]
+ * image / one [H][W] mask each; mask_tab NULL = no mask) which the kernels read at run time.  The loop at
+ * s2_registration.py:241-260 fetches another camera's image every iteration (`viewpoint_cam.original_image.cuda()`); with
+ * the iteration captured in a hipGraph the table lets a replay name that image by rewriting 8 bytes instead of copying it
+ * into a static buffer.  No reference counterpart. */
+int ggs_photometric_forward_tab(int n_views, int H, int W, const float* img, const float* const* gt_tab,
+                                const float* const* mask_tab, float* sums, void* scratch, void* stream);
+int ggs_photometric_backward_tab(int n_views, int H, int W, const float* img, const float* const* gt_tab,
+                                 const float* const* mask_tab, const void* scratch, const float* weights, float* dL_dimg,
+                                 void* stream);
 
 /*
  * Mean squared distance of every point to its 3 nearest neighbours (self excluded) -- replaces
@@ -280,6 +290,12 @@ int ggs_visibility(int P, int F, int n_verts, const float* verts, const int64_t*
  * preprocess_bwd, order_tiles} and returns the count (8). */
 int ggs_profile_enable(int on);
 int ggs_profile_read(float* ms, int n);
+
+/* Introspection (bench.py's compute-side roofline; not part of the reference's interface): *count (device, 8 bytes) <-
+ * the number of (Gaussian, pixel) pairs the forward that filled geom / bin / img blended = the pairs its backward
+ * differentiates.  Walks the forward's lists with the backward's own tests; a few hundred microseconds, never on a timed path. */
+int ggs_count_blends(const GgsParams* p, const void* geom, const void* bin, size_t bin_capacity, const void* img,
+                     unsigned long long* count, void* stream);
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* ggs_last_error(void);

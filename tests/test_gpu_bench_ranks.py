@@ -45,3 +45,74 @@ def test_bench_spawns_its_ranks_and_sums_gradients(tmp_path, graph):
     assert g1.shape == g2.shape and float(g1.abs().sum()) > 0
     rel = float((g1.double() - g2.double()).abs().sum() / g1.double().abs().sum())
     assert rel < 1e-6, rel
+
+
+def test_two_rank_bucket_against_the_oracle_at_config3_size(tmp_path):
+    """BASELINE configs[2] at its own size: 100 000 mesh-bound Gaussians, 1920x1080, the inner loop of
+    s2_registration.py:238-327 with the views sharded over TWO ranks (views[rank::2], one captured step per rank, one
+    all-reduce of the flat bucket [mesh.v | _xyz | f_dc | f_rest | opacity | scaling | rotation]).  The all-reduced bucket
+    rank 0 dumps is compared, tensor by tensor, with the ORACLE pipeline evaluated independently on the host:
+    host_oracle.mesh_bind (autograd) -> C oracle forward + backward of every view with the same seeded dL/dimage ->
+    gradients summed over the views in fp64 -> autograd back to the parameters and mesh.v.  <= 1e-4 relative L1 each."""
+    import math
+
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "gaussian-garments_amd"))
+    from ggsplat import synthetic as S
+    from oracle import host_oracle as HO
+    from oracle.c_oracle import COracle
+
+    n_views, W, H = 8, 1920, 1080
+    dump = str(tmp_path / "two_rank.pt")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+                        "--views", str(n_views), "--steps", "1", "--warmup", "1", "--cpu-views", "0", "--loop-views", "0",
+                        "--extra-configs", "0", "--dump-grads", dump], capture_output=True, text=True, timeout=1500, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert line["n_gpus"] == 2 and [r["views"] for r in line["config"]["ranks"]] == [4, 4]
+    assert "100000 mesh-bound" in line["config"]["workload"] and "1920x1080" in line["config"]["workload"]
+    flat = torch.load(dump).double()
+
+    # the same scene, built the way bench.py builds it
+    verts, faces = S.skirt_mesh(200, 250)
+    Fn = faces.shape[0]
+    params = S.skirt_gaussian_params(Fn, sh_degree=0)
+    cams = S.rig_cameras(n_rings=1, n_az=n_views, width=W, height=H, f=1500.0)[:n_views]
+    w_img = torch.randn(3, H, W, generator=torch.Generator().manual_seed(1234))
+    names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
+    leaf = {n: params[n].clone().requires_grad_(True) for n in names}
+    mv = verts.clone().requires_grad_(True)
+    xyz, scaling, rot = HO.mesh_bind(mv, faces, params["binding"], leaf["_xyz"], leaf["_scaling"], leaf["_rotation"])
+    opacity = torch.sigmoid(leaf["_opacity"])
+    shs = torch.cat((leaf["_features_dc"], leaf["_features_rest"]), 1)
+    keys = ("means3D", "scales", "rotations", "opacities", "shs")
+    tensors = (xyz, scaling, rot, opacity, shs)
+    acc = {k: np.zeros(tuple(t.shape), np.float64) for k, t in zip(keys, tensors)}
+    for c in cams:
+        co = COracle(means3D=xyz.detach(), opacities=opacity.detach(), shs=shs.detach(), scales=scaling.detach(),
+                     rotations=rot.detach(), viewmatrix=c.world_view_transform, projmatrix=c.full_proj_transform,
+                     campos=c.camera_center, bg=torch.zeros(3), W=W, H=H, tanfovx=math.tan(c.FoVx * 0.5),
+                     tanfovy=math.tan(c.FoVy * 0.5), sh_degree=0)
+        g = co.backward(w_img)
+        for k in keys:
+            acc[k] += np.asarray(g[k], np.float64).reshape(acc[k].shape)
+        co.close()
+    torch.autograd.backward(list(tensors), [torch.from_numpy(acc[k]).float() for k in keys])
+    ref = [mv.grad] + [leaf[n].grad if leaf[n].grad is not None else torch.zeros_like(leaf[n]) for n in names]
+    assert sum(r.numel() for r in ref) == flat.numel()
+    o = 0
+    errs = {}
+    for name, r in zip(["mesh.v"] + names, ref):
+        n = r.numel()
+        if n:
+            a = flat[o:o + n]
+            errs[name] = float((a - r.reshape(-1).double()).abs().sum() / (r.double().abs().sum() + 1e-30))
+        o += n
+    print("\n[config 3, 2 ranks x 4 views, 100k / 1080p] all-reduced bucket vs oracle pipeline, relative L1:",
+          {k: f"{v:.2e}" for k, v in errs.items()})
+    assert float(flat.abs().sum()) > 0
+    for name, e in errs.items():
+        assert e <= 1e-4, (name, e)

@@ -85,21 +85,61 @@ def _chain(co, img, dimg, tensors, shapes, leaves):
     loss gradient `dimg` against the host oracle's `img.grad`, <= 1e-4 -- and the rasterizer + binding chain consumes the
     SAME `dimg` on both sides.  (Chaining the two oracles instead would compare position gradients that cancel to ~1 % of
     their per-pixel terms under a smooth loss gradient against the un-cancelled response to the ~2e-6 fp32 noise between
-    two loss implementations: tools/dbg/fullsize_grad_noise.py.)
-    `leaves` already hold the gradients of the hinge terms; returns the oracle's raw gradients and, per leaf, the
-    element-wise magnitude |hinge part| + |photometric part| (the scale rounding errors are relative to: the two parts
-    can have opposite signs, e.g. on `_opacity`, and a ratio to their cancelled sum would measure the cancellation)."""
+    two loss implementations: tools/dbg/fullsize_grad_noise.py.)  That END-TO-END chain -- the host oracle's own dL/dimage
+    through the same oracle backward -- is evaluated as well and returned, so that the number the stage-wise argument
+    avoids is printed and bounded too.
+    `leaves` already hold the gradients of the hinge terms.  Returns the oracle's raw rasterizer gradients, per leaf the
+    element-wise magnitude |hinge part| + |photometric part| (the scale rounding errors are relative to: the two parts can
+    have opposite signs, e.g. on `_opacity`, and a ratio to their cancelled sum would measure the cancellation), and per
+    leaf the end-to-end gradient (hinge + photometric part driven by the oracle's own loss gradient).  On return
+    `leaf.grad` = hinge + stage-wise photometric part."""
     assert rel_l1(dimg, img.grad) <= REL_L1_TOL
     hinge = [None if t.grad is None else t.grad.clone() for t in leaves]
-    g = co.backward(dimg.numpy())
     keys = ("means3D", "scales", "rotations", "opacities", "shs")
-    torch.autograd.backward(list(tensors), [torch.from_numpy(g[k]).reshape(s) for k, s in zip(keys, shapes)])
-    scale = [t.grad.abs() if h is None else h.abs() + (t.grad - h).abs() for t, h in zip(leaves, hinge)]
-    return g, scale
+
+    def photometric(d_image):
+        gr = co.backward(d_image.numpy())
+        parts = torch.autograd.grad(list(tensors), leaves, [torch.from_numpy(gr[k]).reshape(sh) for k, sh in zip(keys, shapes)],
+                                    retain_graph=True, allow_unused=True)
+        return gr, [torch.zeros_like(t) if p is None else p for t, p in zip(leaves, parts)]
+
+    g, stage = photometric(dimg)
+    _, e2e = photometric(img.grad.detach())
+    scale = []
+    for t, h, ps in zip(leaves, hinge, stage):
+        t.grad = ps.clone() if h is None else h + ps
+        scale.append(ps.abs() if h is None else h.abs() + ps.abs())
+    end_to_end = [pe if h is None else h + pe for h, pe in zip(hinge, e2e)]
+    return g, scale, end_to_end
 
 
 def _grad_err(gpu, ref, scale) -> float:
     return float((gpu.detach().cpu().double() - ref.double()).abs().sum() / (scale.double().sum() + 1e-30))
+
+
+# Bounds of the two additional numbers per leaf (measured on MI355X, printed by the tests with -s):
+#   strict   = sum |gpu - oracle| / sum |oracle|   with the SAME dL/dimage on both sides (stage-wise inputs); differs from the
+#              asserted stage-wise metric only where the hinge and the photometric part cancel (`_opacity`, `_scaling`)
+#   end2end  = the same ratio against the chain driven by the host oracle's OWN loss gradient (nothing shared but the inputs)
+STRICT_TOL = 1e-4
+END_TO_END_TOL = 5e-4
+
+
+def _report_and_bound(tag, names, gpu, leaves, scale, end_to_end):
+    rows = []
+    for name, a, b, sc, e in zip(names, gpu, leaves, scale, end_to_end):
+        a64 = a.detach().cpu().double()
+        stage = _grad_err(a, b.grad, sc)
+        strict = float((a64 - b.grad.double()).abs().sum() / (b.grad.double().abs().sum() + 1e-30))
+        e2e = float((a64 - e.double()).abs().sum() / (e.double().abs().sum() + 1e-30))
+        rows.append((name, stage, strict, e2e))
+    print(f"\n[{tag}] relative L1 per leaf: stage-wise (asserted <= {REL_L1_TOL:g}) | strict (<= {STRICT_TOL:g}) | end-to-end (<= {END_TO_END_TOL:g})")
+    for name, stage, strict, e2e in rows:
+        print(f"  {name:16s} {stage:.3e} | {strict:.3e} | {e2e:.3e}")
+    for name, stage, strict, e2e in rows:
+        assert stage <= REL_L1_TOL, (name, "stage-wise", stage)
+        assert strict <= STRICT_TOL, (name, "strict", strict)
+        assert e2e <= END_TO_END_TOL, (name, "end-to-end", e2e)
 
 
 @pytest.fixture(scope="module")
@@ -150,7 +190,7 @@ def test_s3_form_full_size_against_the_oracle_pipeline(skirt):
     l_op = F.relu(opt.threshold_opacity - opacity).mean() * opt.lambda_opacity
     (l_img + l_ssim + l_xyz + l_sc + l_op).backward(retain_graph=True)
     leaves = [leaf[n] for n in NAMES] + [mv, xc, sc_]
-    _, scale = _chain(co, img, _gpu_loss_grad(pkg, gt, mask, lam), sel, [t.shape for t in sel], leaves)
+    _, scale, e2e = _chain(co, img, _gpu_loss_grad(pkg, gt, mask, lam), sel, [t.shape for t in sel], leaves)
 
     assert np.array_equal(pkg["radii"].cpu().numpy(), co.radii)
     assert int((co.radii > 0).sum()) > 0.4 * P
@@ -160,8 +200,7 @@ def test_s3_form_full_size_against_the_oracle_pipeline(skirt):
         assert abs(float(out[k]) - float(r)) <= 2e-5 * max(1.0, abs(float(r))), k
     assert float(l_xyz) > 0 and float(l_sc) > 0 and float(l_op) > 0      # every hinge is active
     gpu = [getattr(model, n).grad for n in NAMES] + [model.mesh.v.grad, xo.grad, so.grad]
-    for name, a, b, sc in zip(NAMES + ["mesh.v", "net.xyz_off", "net.sh_off"], gpu, leaves, scale):
-        assert _grad_err(a, b.grad, sc) <= REL_L1_TOL, name
+    _report_and_bound("s3 form, 100k / 1080p", NAMES + ["mesh.v", "net.xyz_off", "net.sh_off"], gpu, leaves, scale, e2e)
     # Gaussians that were masked out receive only the regulariser gradients
     hidden = ~vis_mask
     assert float(model._features_dc.grad.cpu()[hidden].abs().max()) == 0.0
@@ -197,8 +236,8 @@ def test_s2_form_full_size_against_the_oracle_pipeline(skirt):
     l_sc = F.relu(torch.exp(leaf["_scaling"][vis]) - opt.threshold_scale).norm(dim=1).mean() * opt.lambda_scale
     (l_img + l_ssim + l_xyz + l_sc).backward(retain_graph=True)
     leaves = [leaf[n] for n in NAMES if leaf[n].numel()] + [mv]
-    g, scale = _chain(co, img, _gpu_loss_grad(pkg, gt, mask, lam), (xyz, scaling, rot, opacity, shs),
-                      [xyz.shape, scaling.shape, rot.shape, opacity.shape, shs.shape], leaves)
+    g, scale, e2e = _chain(co, img, _gpu_loss_grad(pkg, gt, mask, lam), (xyz, scaling, rot, opacity, shs),
+                           [xyz.shape, scaling.shape, rot.shape, opacity.shape, shs.shape], leaves)
 
     assert np.array_equal(pkg["radii"].cpu().numpy(), co.radii)
     assert rel_l1(pkg["render"], co.color) <= REL_L1_TOL
@@ -206,8 +245,7 @@ def test_s2_form_full_size_against_the_oracle_pipeline(skirt):
         assert abs(float(out[k]) - float(r)) <= 2e-5 * max(1.0, abs(float(r))), k
     names = [n for n in NAMES if leaf[n].numel()] + ["mesh.v"]
     gpu = [getattr(model, n).grad for n in names[:-1]] + [model.mesh.v.grad]
-    for name, a, b, sc in zip(names, gpu, leaves, scale):
-        assert _grad_err(a, b.grad, sc) <= REL_L1_TOL, name
+    _report_and_bound("s2 form, 100k / 1080p", names, gpu, leaves, scale, e2e)
     assert rel_l1(pkg["viewspace_points"].grad, g["means2D"]) <= REL_L1_TOL
     # densification statistics of this one view (scene/gaussian_model.py:410-412)
     ref = torch.zeros(P, 1)

@@ -18,15 +18,23 @@ for c in cams:
     for name in ("world_view_transform", "full_proj_transform", "camera_center"):
         setattr(c, name, getattr(c, name).to(dev))
 bg = torch.zeros(3, device=dev)
-gt = torch.rand(3, H, W, device=dev); mask = (torch.rand(1, H, W, device=dev) > 0.1).float()
+# ground truth = the initial model's own render of each camera + a little noise: the optimisation stays near its starting
+# point however many iterations are timed (against a random image the Gaussians grow without bound and the iteration with them)
+from types import SimpleNamespace
+from ggsplat.render import render
+pipe = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+with torch.no_grad():
+    m.update_face_coor()
+    gts = [(render(c, m, pipe, bg)["render"] + 0.02 * torch.randn(3, H, W, device=dev)).clamp(0, 1).contiguous() for c in cams]
+mask = (torch.rand(1, H, W, device=dev) > 0.1).float()
 step = GraphedRegistrationStep(m, W, H, bg)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-for c in cams[:2]:
-    step(c, gt, mask)
+for i in range(2):
+    step(cams[i], gts[i], mask)
 torch.cuda.synchronize()
 t = time.perf_counter()
 for i in range(n):
-    step(cams[i % len(cams)], gt, mask)
+    step(cams[i % len(cams)], gts[i % len(cams)], mask)
 torch.cuda.synchronize()
 dt = time.perf_counter() - t
 print(f"graphed s2 step: {n/dt:.1f} it/s, {dt/n*1e3:.3f} ms/it, recaptures {step.recaptures}")
