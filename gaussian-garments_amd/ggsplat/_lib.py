@@ -46,6 +46,8 @@ _SIGS = {
     "ggs_photometric_forward_tab": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 6),
     "ggs_photometric_backward_tab": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 7),
     "ggs_dist2_3nn": (C.c_int, [C.c_int, _PTR, _PTR, _PTR]),
+    "ggs_dist2_3nn_scratch_bytes": (C.c_size_t, [C.c_int]),
+    "ggs_dist2_3nn_grid": (C.c_int, [C.c_int, _PTR, _PTR, _PTR, _PTR]),
     "ggs_fused_bias_act": (C.c_int, [C.c_size_t, _PTR, _PTR, _PTR, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _PTR, _PTR]),
     "ggs_fused_bias_act_t": (C.c_int, [C.c_int, C.c_size_t, _PTR, _PTR, _PTR, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, _PTR, _PTR]),
     "ggs_upfirdn2d_t": (C.c_int, [C.c_int] * 5 + [_PTR, _PTR] + [C.c_int] * 10 + [_PTR, _PTR]),

@@ -23,6 +23,35 @@ def test_dist2_matches_kdtree(P):
     assert np.allclose(out, ref, rtol=2e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("kind", ["gauss", "surface", "clustered", "planar", "line", "identical"])
+def test_grid_search_equals_brute_force_bit_for_bit(kind):
+    """ggs_dist2_3nn_grid against the O(P^2) kernel: the same fp32 distance expression over a superset of the true
+    neighbours -> identical bits, whatever the cloud looks like (volume, thin surface like the garment, clusters with far
+    outliers, degenerate extents, all points equal) -- and against the KD-tree."""
+    from simple_knn._C import distCUDA2
+    from ggsplat import synthetic as S
+    g = torch.Generator().manual_seed(7)
+    if kind == "gauss":
+        pts = torch.randn(60_000, 3, generator=g)
+    elif kind == "surface":
+        v, f = S.skirt_mesh()
+        pts = v[f].mean(1)                                                   # 100k face centres of the skirt tube
+    elif kind == "clustered":
+        pts = torch.cat([torch.randn(20_000, 3, generator=g) * 0.01, torch.randn(20_000, 3, generator=g) * 0.01 + 5.0,
+                         torch.randn(50, 3, generator=g) * 100.0])
+    elif kind == "planar":
+        pts = torch.cat([torch.rand(30_000, 2, generator=g), torch.zeros(30_000, 1)], 1)
+    elif kind == "line":
+        pts = torch.cat([torch.rand(5_000, 1, generator=g), torch.full((5_000, 2), 0.25)], 1)
+    else:
+        pts = torch.full((3_000, 3), 1.5)
+    a = distCUDA2(pts.cuda())
+    b = distCUDA2(pts.cuda(), brute_force=True)
+    assert torch.equal(a, b)
+    if kind != "identical":
+        assert np.allclose(a.cpu().numpy(), _ref(pts.numpy()), rtol=2e-5, atol=1e-9)
+
+
 def test_duplicates_and_model_init():
     from simple_knn._C import distCUDA2
     from ggsplat.mesh_gaussian_model import MeshGaussianModel
