@@ -513,7 +513,35 @@ def main():
                 s3step(c, gt_i, gt_mask)
             torch.cuda.synchronize(dev)
             s3_vps = len(lcams) / (time.perf_counter() - t1)
-            del s3step, m3, net3, o3, gts3
+            del s3step, net3, o3
+            # config 4 with a NETWORK in the loop: the same captured s3 iteration, offsets predicted by a StyleGAN2-style U-Net
+            # (ggsplat.stylenet.StyleUNetLite: texture 512 -- the reference's default, s3_appearance.py:61 --, 4 -> 51 channels,
+            # style_dim 512, the channel table of styleunet.py:662-672) running on the HIP ops of row f3 and sampled at
+            # per-Gaussian UV coordinates.  It is this repo's own stand-in of the reference's StyleUNet, not that network.
+            s3net_vps = s3net_desc = None
+            if args.extra_configs:
+                from ggsplat.stylenet import StyleUNetLite, TexelOffsets
+                torch.manual_seed(7)
+                unet = StyleUNetLite(size=512, in_ch=4, out_ch=51, style_dim=512, impl="hip").to(dev)
+                net4 = TexelOffsets(unet, torch.rand(Fn, 2, generator=g3).to(dev), 16, vis3, torch.randn(1, 4, 512, 512, generator=g3).to(dev)).to(dev)
+                o4 = GraphAdam([{"params": list(net4.parameters()), "lr": 1e-4, "name": "net"},
+                                {"params": [m3._opacity], "lr": 1e-2, "name": "opacity"}, {"params": [m3._scaling], "lr": 2e-3, "name": "scaling"},
+                                {"params": [m3._features_dc], "lr": 2.5e-3, "name": "f_dc"}], lr=0.0, eps=1e-15)
+                s4 = GraphedAppearanceStep(m3, net4, W, H, bg, o4)
+                for c, gt_i in zip(lcams[:2], gts3):
+                    s4(c, gt_i, gt_mask)
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for c, gt_i in zip(lcams[:8], gts3):
+                    s4(c, gt_i, gt_mask)
+                torch.cuda.synchronize(dev)
+                s3net_vps = 8 / (time.perf_counter() - t1)
+                s3net_desc = (f"s3 iteration (config-4 form: {Fn} texel-bound Gaussians, K = 16, ~50 % visible, 1920x1080, five-term loss, "
+                              f"guarded Adam) with StyleUNetLite(texture 512, 4 -> 51 channels, style_dim 512, "
+                              f"{sum(p.numel() for p in unet.parameters()) / 1e6:.1f} M parameters) on the HIP fused_bias_act / upfirdn2d "
+                              f"ops producing the offsets; one hipGraph replay per iteration")
+                del s4, net4, unet, o4
+            del m3, gts3
 
         # ---- CPU baseline: the C oracle on the host cores, bounded sample of the same views ----
         cpu = None
@@ -564,6 +592,8 @@ def main():
             extras = {"config2_sh3": extra_config("config 2 with SH degree 3 (the s3 setting)", dev, sh_degree=3, n_around=200,
                                                    n_rows=250, W=1920, H=1080, views=64, chunk=32, steps=4)}
             torch.cuda.empty_cache()
+            if args.loop_views > 0 and s3net_vps is not None:
+                extras["config4_s3_with_network"] = {"workload": s3net_desc, "value": round(s3net_vps, 2), "unit": "iterations/s"}
             extras["config5_stress"] = extra_config("config 5 (stress)", dev, sh_degree=3, n_around=500, n_rows=500, W=3840,
                                                     H=2160, views=32, chunk=16, steps=3)
             torch.cuda.empty_cache()

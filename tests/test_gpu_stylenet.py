@@ -1,0 +1,126 @@
+"""The two StyleGAN2 ops of row f3 exercised AS A NETWORK: ggsplat.stylenet expresses the autograd of
+`fused.fused_bias_act` and `upfirdn2d.upfirdn2d` -- forward, backward, double backward -- through the same two forward ops,
+the way scene/styleunet/fused_act.py:33-130 and scene/styleunet/upfirdn2d.py:98-184 do, and stacks StyleGAN2 blocks on them
+at the channel table of scene/styleunet/styleunet.py:662-672.  Everything is compared with the same modules on their
+plain-PyTorch (`impl="native"`) paths: same weights, same inputs, values and every parameter gradient."""
+import copy
+import time
+
+import pytest
+import torch
+
+from ggsplat import stylenet as SN
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().sum() / (b.double().abs().sum() + 1e-30))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+def test_bias_act_all_orders(dtype):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(3, 7, 9, 11, generator=g, dtype=dtype).cuda().requires_grad_(True)
+    b = torch.randn(7, generator=g, dtype=dtype).cuda().requires_grad_(True)
+    w = torch.randn(3, 7, 9, 11, generator=g, dtype=dtype).cuda()
+    v = torch.randn(3, 7, 9, 11, generator=g, dtype=dtype).cuda()
+    res = []
+    for impl in ("hip", "native"):
+        y = SN.bias_act(x, b, impl=impl)
+        gx, gb = torch.autograd.grad((y * w).sum(), (x, b), create_graph=True)
+        (ggw,) = torch.autograd.grad((gx * v).sum(), (w,), allow_unused=True) if w.requires_grad else (None,)
+        # second order: d/dx of <gx, v> is zero almost everywhere (piecewise linear); what is non-trivial is the dependence of
+        # gx on the incoming gradient, i.e. the backward of the backward: check it through a differentiable upstream gradient
+        up = w.clone().requires_grad_(True)
+        gx2 = torch.autograd.grad(SN.bias_act(x, b, impl=impl), x, up, create_graph=True)[0]
+        (gup,) = torch.autograd.grad((gx2 * v).sum(), up)
+        res.append((y.detach(), gx.detach(), gb.detach(), gup.detach()))
+    # (alpha and the gain cross the C ABI as `float`, like upstream's op: sqrt(2) carries fp32 rounding in the double path too)
+    tol = 1e-6 if dtype is torch.float32 else 1e-7
+    for a, r in zip(*res):
+        assert _rel(a, r) <= tol
+
+
+CASES = [("blur", SN.binomial_kernel(), 1, 1, (2, 1)), ("up", SN.binomial_kernel() * 4, 2, 1, (2, 1)),
+         ("down", SN.binomial_kernel(), 1, 2, (2, 2)), ("haar", SN.haar_kernels()[1], 1, 2, (0, 0)),
+         ("ihaar", SN.haar_kernels()[2], 2, 1, (1, 0)), ("blur_up_tail", SN.binomial_kernel() * 4, 1, 1, (1, 1))]
+
+
+@pytest.mark.parametrize("name,k,up,down,pad", CASES, ids=[c[0] for c in CASES])
+def test_resample2d_all_orders(name, k, up, down, pad):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 5, 18, 22, generator=g).cuda().requires_grad_(True)
+    k = k.cuda()
+    res = []
+    for impl in ("hip", "native"):
+        y = SN.resample2d(x, k, up, down, pad, impl=impl)
+        w = torch.randn(y.shape, generator=torch.Generator().manual_seed(3)).cuda().requires_grad_(True)
+        (gx,) = torch.autograd.grad((y * w).sum(), x, create_graph=True)
+        v = torch.randn(x.shape, generator=torch.Generator().manual_seed(4)).cuda()
+        (gw,) = torch.autograd.grad((gx * v).sum(), w)          # backward of the backward = the forward operator applied to v
+        res.append((y.detach(), gx.detach(), gw.detach()))
+    for a, r in zip(*res):
+        assert a.shape == r.shape and _rel(a, r) <= 2e-6
+
+
+def _pair(size, out_ch, style_dim, channels=None, seed=5):
+    torch.manual_seed(seed)
+    hip = SN.StyleUNetLite(size=size, in_ch=4, out_ch=out_ch, style_dim=style_dim, impl="hip", channels=channels).cuda()
+    nat = SN.StyleUNetLite(size=size, in_ch=4, out_ch=out_ch, style_dim=style_dim, impl="native", channels=channels).cuda()
+    nat.load_state_dict(copy.deepcopy(hip.state_dict()))
+    return hip, nat
+
+
+def _fwd_bwd(net, cond, style, w):
+    for p in net.parameters():
+        p.grad = None
+    out = net(cond, style)
+    (out * w).sum().backward()
+    return out.detach(), {n: p.grad.detach().clone() for n, p in net.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize("dtype", [torch.float64, torch.float32])
+def test_small_network_values_and_every_gradient(dtype):
+    """Same weights, same inputs, HIP ops against native ops.  In double every parameter gradient agrees to the 1e-7 of the
+    fp32 gain constant that crosses the C ABI; in single the texture agrees to 1e-5 and the gradients to 5e-3 -- a leaky-ReLU
+    unit whose pre-activation is within rounding of zero takes the other slope in one of the two paths, a discrete change that
+    the deepest parameters (the mapping layers feed every modulated convolution) see as ~1e-3; no such flip survives in double."""
+    ch = {k: min(v, 24) for k, v in SN.CHANNELS.items()}
+    hip, nat = _pair(64, 7, 32, ch)
+    hip, nat = hip.to(dtype), nat.to(dtype)
+    g = torch.Generator().manual_seed(6)
+    cond, style = torch.randn(2, 4, 64, 64, generator=g).cuda().to(dtype), torch.randn(2, 32, generator=g).cuda().to(dtype)
+    w = torch.randn(2, 7, 64, 64, generator=g).cuda().to(dtype)
+    oh, gh = _fwd_bwd(hip, cond, style, w)
+    on, gn = _fwd_bwd(nat, cond, style, w)
+    assert oh.shape == (2, 7, 64, 64) and _rel(oh, on) <= (1e-6 if dtype is torch.float64 else 1e-5)
+    assert set(gh) == set(gn) and len(gh) >= 30
+    tol = 1e-6 if dtype is torch.float64 else 5e-3
+    for n in gn:
+        assert _rel(gh[n], gn[n]) <= tol, n
+
+
+def test_reference_channel_table_texture_512():
+    """Texture size 512 (the reference's default, s3_appearance.py:61), 4 -> 51 channels ((3 + 1)^2 * 3 + 3, avatar_net.py:21),
+    style_dim 512, channel table of styleunet.py:662-672: forward + backward on the HIP ops against the native paths, timed."""
+    hip, nat = _pair(512, 51, 512)
+    g = torch.Generator().manual_seed(7)
+    cond, style = torch.randn(1, 4, 512, 512, generator=g).cuda(), torch.randn(1, 512, generator=g).cuda()
+    w = torch.randn(1, 51, 512, 512, generator=g).cuda()
+    oh, gh = _fwd_bwd(hip, cond, style, w)
+    on, gn = _fwd_bwd(nat, cond, style, w)
+    assert oh.shape == (1, 51, 512, 512) and _rel(oh, on) <= 1e-4
+    worst = max(_rel(gh[n], gn[n]) for n in gn)
+    assert worst <= 1e-2, worst                     # fp32, 512^2 pixels: summation order of the conv library + slope flips (see above)
+    times = {}
+    for name, net in (("hip", hip), ("native", nat)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            _fwd_bwd(net, cond, style, w)
+        torch.cuda.synchronize()
+        times[name] = (time.perf_counter() - t0) / 3
+    n_par = sum(p.numel() for p in hip.parameters())
+    print(f"\n[StyleUNetLite 512, {n_par / 1e6:.1f} M parameters] fwd+bwd: HIP ops {times['hip'] * 1e3:.1f} ms, native ops "
+          f"{times['native'] * 1e3:.1f} ms; worst parameter-gradient rel. L1 {worst:.2e}")

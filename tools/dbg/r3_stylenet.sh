@@ -1,0 +1,2 @@
+cd $GRAFT_REPO_ROOT
+timeout 1500 python -m pytest tests/test_gpu_stylenet.py -x -q -s 2>&1 | tail -15
