@@ -39,6 +39,8 @@ def lib():
         _lib.ggo_forward.restype = C.c_void_p
         _lib.ggo_num_rendered.restype = C.c_int64
         _lib.ggo_num_rendered.argtypes = [C.c_void_p]
+        _lib.ggo_num_blended.restype = C.c_int64
+        _lib.ggo_num_blended.argtypes = [C.c_void_p]
         _lib.ggo_free.argtypes = [C.c_void_p]
     return _lib
 
@@ -82,6 +84,7 @@ class COracle:
                                           _p(self.proj), _p(self.campos), _p(self.color), _p(self.depth),
                                           _p(self.alpha), _p(self.radii)))
         self.num_rendered = int(L.ggo_num_rendered(self.h))
+        self.num_blended = int(L.ggo_num_blended(self.h))      # (Gaussian, pixel) pairs the compositing blended
 
     def internals(self) -> Dict[str, np.ndarray]:
         P, W, H = self.P, self.W, self.H

@@ -65,6 +65,7 @@ typedef struct {
     uint8_t *clamped;
     /* binning */
     int64_t N;
+    int64_t n_blended;   /* (Gaussian, pixel) pairs blended by the forward */
     int64_t *tile_start; /* gx*gy+1 */
     uint32_t *list;      /* sorted ids, N */
     /* per pixel */
@@ -317,7 +318,8 @@ void* ggo_forward(const ggo_params* prm, const float* bg, const float* means3D, 
     free(items); free(tcount);
 
     /* compositing (A.1 step 10) */
-#pragma omp parallel for schedule(dynamic, 4)
+    int64_t n_blended = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : n_blended)
     for (int t = 0; t < T; ++t) {
         int tx = t % gx, ty = t / gx;
         int64_t b0 = s->tile_start[t], b1 = s->tile_start[t + 1];
@@ -343,6 +345,7 @@ void* ggo_forward(const ggo_params* prm, const float* bg, const float* means3D, 
                     D += s->depth[id] * w; A += w;
                     Tr = test_T;
                     last = contributor;
+                    n_blended++;
                 }
                 size_t pix = (size_t)py * W + px;
                 s->final_T[pix] = Tr; s->n_contrib[pix] = last;
@@ -352,10 +355,12 @@ void* ggo_forward(const ggo_params* prm, const float* bg, const float* means3D, 
                 out_depth[pix] = D; out_alpha[pix] = A;
             }
     }
+    s->n_blended = n_blended;
     return s;
 }
 
 int64_t ggo_num_rendered(const void* h) { return ((const ggo_state*)h)->N; }
+int64_t ggo_num_blended(const void* h) { return ((const ggo_state*)h)->n_blended; }
 
 /* Copy internals out for tests.  Any pointer may be NULL. */
 void ggo_get_internals(const void* h, float* xy, float* depth, float* conic_op, float* rgb, float* cov3d,

@@ -321,3 +321,36 @@ def test_cov3d_stage_against_the_reference_fixture(tag, mod):
     assert int((a[1] > 0).sum()) > P // 2 and torch.equal(a[1], b[1])
     for x, y in zip((a[0], a[2], a[3]), (b[0], b[2], b[3])):
         assert rel_l1(x, y) <= 1e-5
+
+
+@pytest.mark.parametrize("views", [1, 8])
+def test_count_blends_equals_the_oracles_blended_pairs(views):
+    """ggs_count_blends (the basis of bench.py's compute-side roofline) against the C oracle's own count of the
+    (Gaussian, pixel) pairs its compositing loop blended: one view through the per-quadrant kernels, eight through the
+    per-tile kernels.  Exact up to pairs whose alpha sits within rounding of 1/255 (exp2 on the GPU, expf in the oracle)."""
+    import ctypes as C
+    from ggsplat import _lib, rasterizer as R
+    from ggsplat.synthetic import orbit_cameras, random_gaussians, stack_cameras
+    sc = random_gaussians(4000, sh_degree=0, seed=77)
+    sc["scales"] = sc["scales"] * 4
+    cams = orbit_cameras(views, width=1920 if views > 1 else 320, img_height=1080 if views > 1 else 200,
+                         fx=900.0 if views > 1 else 220.0, fy=900.0 if views > 1 else 220.0,
+                         cx=960.0 if views > 1 else 158.0, cy=540.0 if views > 1 else 101.0)
+    W, H = (1920, 1080) if views > 1 else (320, 200)
+    dev = "cuda"
+    ck = stack_cameras(cams, device=dev)
+    color, radii, depth, alpha, st = R.forward_views(
+        sc["means3D"].to(dev), sc["opacities"].to(dev), sc["shs"].to(dev), None, sc["scales"].to(dev),
+        sc["rotations"].to(dev), None, view=ck["view"], proj=ck["proj"], campos=ck["campos"], tanfov=ck["tanfov"],
+        bg=torch.zeros(3, device=dev), W=W, H=H, sh_degree=0)
+    cnt = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(_lib.lib().ggs_count_blends(C.byref(st.prm), st.geom.data_ptr(), st.bin.data_ptr(), st.cap, st.img.data_ptr(),
+                                           cnt.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), "ggs_count_blends")
+    ref = 0
+    for cam in cams:
+        co = COracle(means3D=sc["means3D"], opacities=sc["opacities"], shs=sc["shs"], scales=sc["scales"],
+                     rotations=sc["rotations"], sh_degree=0, **cam_kwargs(cam, (0, 0, 0)))
+        ref += co.num_blended
+        co.close()
+    got = int(cnt.item())
+    assert ref > 10000 and abs(got - ref) <= max(2, int(2e-5 * ref)), (got, ref)
