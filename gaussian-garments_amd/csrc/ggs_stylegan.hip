@@ -138,9 +138,12 @@ __global__ __launch_bounds__(256) void k_upfirdn2d(UpfirdnArgs<T> a) {
 // input sample px / UP where px is a multiple of UP.  The tile needs px in [px_lo, px_lo + (63 DOWN + KW - 1)], i.e.
 // input columns ix_lo = ceil(px_lo / UP) ... ; the LDS patch stores them densely, zero where the image ends.
 #define UFD_TW 64
-// tile height: 8 outputs per lane (two groups of 4 rows) where the patch stays under 16 KB of LDS, else 4
-template <typename A, int UP, int DOWN, int K> struct UfdTile {
-    static constexpr int W = ((UFD_TW - 1) * DOWN + K - 1) / UP + 2;
+// tile height: 8 outputs per lane (two groups of 4 rows) where the patch stays under 16 KB of LDS, else 4.
+// COLS = output columns per lane: 1, or 2 for half (a 128-column tile: the two outputs leave as ONE 4-byte store and the
+// patch is staged with 4-byte loads -- a half tile of 64 columns keeps half the bytes in flight per workgroup that a float
+// tile does, and the kernel is bound by exactly that: 2.0 against 3.0 TB/s for the same op in round 2).
+template <typename A, int UP, int DOWN, int K, int COLS, bool VEC = (COLS == 2)> struct UfdTile {
+    static constexpr int W = ((UFD_TW * COLS - 1) * DOWN + K - 1) / UP + 2 + (VEC ? 1 : 0);     // (+1: a patch staged in column pairs starts on an even input column)
     static constexpr int H32 = ((32 - 1) * DOWN + K - 1) / UP + 2;
     static constexpr int TH = (size_t)H32 * (W + 1) * sizeof(A) <= 16 * 1024 ? 32 : 16;      // measured: the 35 KB patches of down = 2 lose more in occupancy (3.2 -> 1.9 TB/s) than the shorter halo gains
     static constexpr int H = ((TH - 1) * DOWN + K - 1) / UP + 2;
@@ -172,22 +175,41 @@ __device__ __forceinline__ void ufd_rows(const A* __restrict__ base, const A (&w
     }
 }
 
-template <typename T, int UP, int DOWN, int KH, int KW>
+// VEC (half only, even in_w): the patch is staged in pairs of input columns, one 4-byte load each.
+template <typename T, int UP, int DOWN, int KH, int KW, int COLS, bool VEC>
 __global__ __launch_bounds__(256) void k_upfirdn2d_tile(UpfirdnArgs<T> a) {
     typedef typename Acc<T>::type A;
-    typedef UfdTile<A, UP, DOWN, KH> Tile;
+    typedef UfdTile<A, UP, DOWN, KH, COLS, VEC> Tile;
     constexpr int PW = Tile::W, PH = Tile::H, LD = PW + 1, TH = Tile::TH, G = TH / 16;      // G groups of 4 rows per lane
+    constexpr int TW = UFD_TW * COLS;
     __shared__ A patch[PH * LD];
-    const int ox0 = blockIdx.x * UFD_TW, oy0 = blockIdx.y * TH, m = blockIdx.z;
+    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH, m = blockIdx.z;
     const int px_lo = ox0 * DOWN - a.pad_x0, py_lo = oy0 * DOWN - a.pad_y0;
-    const int ix_lo = ceil_div_up(px_lo, UP), iy_lo = ceil_div_up(py_lo, UP);
+    const int ix_lo = VEC ? (ceil_div_up(px_lo, UP) & ~1) : ceil_div_up(px_lo, UP), iy_lo = ceil_div_up(py_lo, UP);
     const T* src = a.in + (size_t)m * a.in_h * a.in_w;
-    for (int i = threadIdx.x; i < PW * PH; i += 256) {
-        const int r = i / PW, c = i - r * PW;              // PW is a compile-time constant: multiply-shift, once per sample
-        const int ix = ix_lo + c, iy = iy_lo + r;
-        A v = (A)0;
-        if (ix >= 0 && ix < a.in_w && iy >= 0 && iy < a.in_h) v = ld(src + (size_t)iy * a.in_w + ix);
-        patch[r * LD + c] = v;
+    if constexpr (VEC) {
+        // pairs of input columns (even, odd) as one 4-byte load: in_w is even (launch condition), so a pair is inside the
+        // image or outside it as a whole and every pair is 4-byte aligned
+        constexpr int PW2 = (PW + 1) / 2;
+        for (int i = threadIdx.x; i < PW2 * PH; i += 256) {
+            const int r = i / PW2, c = 2 * (i - r * PW2);
+            const int ix = ix_lo + c, iy = iy_lo + r;
+            A v0 = (A)0, v1 = (A)0;
+            if (ix >= 0 && ix < a.in_w && iy >= 0 && iy < a.in_h) {
+                const __half2 h2 = *reinterpret_cast<const __half2*>(src + (size_t)iy * a.in_w + ix);
+                v0 = __low2float(h2); v1 = __high2float(h2);
+            }
+            patch[r * LD + c] = v0;
+            if (c + 1 < PW) patch[r * LD + c + 1] = v1;
+        }
+    } else {
+        for (int i = threadIdx.x; i < PW * PH; i += 256) {
+            const int r = i / PW, c = i - r * PW;              // PW is a compile-time constant: multiply-shift, once per sample
+            const int ix = ix_lo + c, iy = iy_lo + r;
+            A v = (A)0;
+            if (ix >= 0 && ix < a.in_w && iy >= 0 && iy < a.in_h) v = ld(src + (size_t)iy * a.in_w + ix);
+            patch[r * LD + c] = v;
+        }
     }
     A w[KH][KW];                                            // flipped FIR: tap (i, j) multiplies kernel[KH-1-i][KW-1-j]
 #pragma unroll
@@ -196,12 +218,16 @@ __global__ __launch_bounds__(256) void k_upfirdn2d_tile(UpfirdnArgs<T> a) {
         for (int j = 0; j < KW; ++j) w[i][j] = ld(a.kernel + (KH - 1 - i) * KW + (KW - 1 - j));
     __syncthreads();
     const int tx = threadIdx.x & (UFD_TW - 1), ty = threadIdx.x >> 6;
-    const int ox = ox0 + tx;
+    const int ox = ox0 + tx * COLS;
     if (ox >= a.out_w) return;
     // first tap on the up-sampling lattice and its patch column: px = ox DOWN + j - pad_x0 must be a multiple of UP
-    const int pxb = ox * DOWN - a.pad_x0;
-    const int j0 = UP == 1 ? 0 : (pxb & 1);                 // pxb + j even  <=>  j has the parity of pxb
-    const int cx = (UP == 1 ? pxb : (pxb + j0) >> 1) - ix_lo;
+    int j0[COLS], cx[COLS];
+#pragma unroll
+    for (int c = 0; c < COLS; ++c) {
+        const int pxb = (ox + c) * DOWN - a.pad_x0;
+        j0[c] = UP == 1 ? 0 : (pxb & 1);                    // pxb + j even  <=>  j has the parity of pxb
+        cx[c] = (UP == 1 ? pxb : (pxb + j0[c]) >> 1) - ix_lo;
+    }
     const int p0 = UP == 1 ? 0 : (a.pad_y0 & 1);            // = pyb & 1 for every lane (oyb is a multiple of 4)
     T* dst = a.out + (size_t)m * a.out_h * a.out_w + ox;
 #pragma unroll
@@ -210,13 +236,22 @@ __global__ __launch_bounds__(256) void k_upfirdn2d_tile(UpfirdnArgs<T> a) {
         if (oyb >= a.out_h) break;
         const int pyb = oyb * DOWN - a.pad_y0;
         const int cy = (UP == 1 ? pyb : (pyb - p0) >> 1) - iy_lo;
-        const A* base = patch + cy * LD + cx;
-        A acc[4];
-        if (p0) ufd_rows<A, UP, DOWN, KH, KW, 1, LD>(base, w, j0, acc);
-        else ufd_rows<A, UP, DOWN, KH, KW, 0, LD>(base, w, j0, acc);
+        A acc[COLS][4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            if (oyb + r < a.out_h) st(dst + (size_t)(oyb + r) * a.out_w, acc[r]);
+        for (int c = 0; c < COLS; ++c) {
+            const A* base = patch + cy * LD + cx[c];
+            if (p0) ufd_rows<A, UP, DOWN, KH, KW, 1, LD>(base, w, j0[c], acc[c]);
+            else ufd_rows<A, UP, DOWN, KH, KW, 0, LD>(base, w, j0[c], acc[c]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            if (oyb + r >= a.out_h) break;
+            if constexpr (COLS == 2) {                       // out_w is even (launch condition): ox + 1 < out_w, 4-byte aligned
+                *reinterpret_cast<__half2*>(dst + (size_t)(oyb + r) * a.out_w) = __floats2half2_rn(acc[0][r], acc[1][r]);
+            } else {
+                st(dst + (size_t)(oyb + r) * a.out_w, acc[0][r]);
+            }
+        }
     }
 }
 
@@ -226,12 +261,32 @@ int launch_upfirdn(const UpfirdnArgs<T>& a, hipStream_t s) {
     const bool sq = a.up_x == a.up_y && a.down_x == a.down_y && a.kh == a.kw && a.minor == 1 && a.major <= 65535;
     typedef typename Acc<T>::type A;
     const int key = sq && a.out_h / 16 + 1 <= 65535 ? a.up_x * 100 + a.down_x * 10 + a.kh : -1;
+    // half: 4-byte accesses need even row pitches, even plane sizes and 4-byte aligned bases
+    const bool vec_in = sizeof(T) == 2 && (a.in_w & 1) == 0 && (reinterpret_cast<uintptr_t>(a.in) & 3) == 0 && (((size_t)a.in_h * a.in_w) & 1) == 0;
+    const bool vec_out = sizeof(T) == 2 && (a.out_w & 1) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 3) == 0 && (((size_t)a.out_h * a.out_w) & 1) == 0;
+    (void)vec_in; (void)vec_out;
     switch (key) {
 #define UFD_CASE(UP, DOWN, K) \
         case UP * 100 + DOWN * 10 + K: {                                                                                         \
-            constexpr int TH = UfdTile<A, UP, DOWN, K>::TH;                                                                          \
+            if constexpr (sizeof(T) == 2) {                                                                                       \
+                /* half: two output columns per lane (up-sampling and same-size filters; a down-sampling tile of 128 columns  */ \
+                /* needs a 36 KB patch and measured slower) or at least the column-pair staging                                */ \
+                if (vec_in && vec_out && DOWN == 1) {                                                                             \
+                    constexpr int TH2 = UfdTile<A, UP, DOWN, K, 2, true>::TH;                                                    \
+                    const dim3 grid2((unsigned)((a.out_w + 2 * UFD_TW - 1) / (2 * UFD_TW)), (unsigned)((a.out_h + TH2 - 1) / TH2), (unsigned)a.major); \
+                    hipLaunchKernelGGL((k_upfirdn2d_tile<T, UP, DOWN, K, K, 2, true>), grid2, dim3(256), 0, s, a);               \
+                    break;                                                                                                        \
+                }                                                                                                                 \
+                if (vec_in) {                                                                                                     \
+                    constexpr int TH1 = UfdTile<A, UP, DOWN, K, 1, true>::TH;                                                    \
+                    const dim3 grid1((unsigned)((a.out_w + UFD_TW - 1) / UFD_TW), (unsigned)((a.out_h + TH1 - 1) / TH1), (unsigned)a.major); \
+                    hipLaunchKernelGGL((k_upfirdn2d_tile<T, UP, DOWN, K, K, 1, true>), grid1, dim3(256), 0, s, a);               \
+                    break;                                                                                                        \
+                }                                                                                                                 \
+            }                                                                                                                     \
+            constexpr int TH = UfdTile<A, UP, DOWN, K, 1, false>::TH;                                                                \
             const dim3 grid((unsigned)((a.out_w + UFD_TW - 1) / UFD_TW), (unsigned)((a.out_h + TH - 1) / TH), (unsigned)a.major);   \
-            hipLaunchKernelGGL((k_upfirdn2d_tile<T, UP, DOWN, K, K>), grid, dim3(256), 0, s, a);                                     \
+            hipLaunchKernelGGL((k_upfirdn2d_tile<T, UP, DOWN, K, K, 1, false>), grid, dim3(256), 0, s, a);                           \
         } break;
         UFD_CASE(1, 1, 4) UFD_CASE(2, 1, 4) UFD_CASE(1, 2, 4)      // Blur, Upsample, Downsample (+ their backward passes)
         UFD_CASE(1, 2, 2) UFD_CASE(2, 1, 2)                        // Haar, inverse Haar
