@@ -15,10 +15,12 @@
 //     folds the 9-10 values into ONE register (each total in its own lane), and a single vector
 //     float-atomic instruction adds them to the splat's GradRec.
 //
-// Roofline: HBM nominally (algorithmic bytes: forward N*48 B gathers + 28 B/pixel outputs; backward N*48 +
-// 20 B/pixel + N*36 B of atomics); measured: bound by VALU instruction issue (SQ counters, profiles/r01_sq_counters.md:
-// INSTS_VALU x 4 cycles fills 96-100 % of the kernel time).  Per (tile, splat): ~10 VALU of overhead + per active
-// quadrant 11 (alpha test) + 12 (blend) forward; ~13 + 21 (reduction) + 35 per quadrant backward.
+// Roofline: HBM nominally (algorithmic bytes per view: forward 44 N + 28 HW + 16 T, backward 20 HW + 44 N + 36 P_vis); in practice
+// both kernels are bound by VALU issue -- rocprofv3's VALUBusy is 126 % / 97 % for backward / forward (profiles/r03_sh0_valu.md),
+// their HBM traffic stays below / near the algorithmic count.  Priced per instruction class (profiles/r02_valu_issue_rates.md,
+// profiles/r02_isa_audit.md): backward ~25 cycles of per-entry overhead + ~115 per active quadrant (1.55 per entry) + ~110 for the
+// 64-lane reduction; forward ~44 per visited quadrant (2.09 per entry) + ~40 per blended one.  What other mappings would cost
+// (splat-major / systolic, larger tiles, MFMA moments) and why none was adopted: profiles/r03_bwd_mapping_study.md.
 #include "ggs_render_common.h"
 
 namespace {

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Everything profiles/ holds for one round, from ONE build, in one GPU-box call:  tools/profile_round.sh r02
+# Everything profiles/ holds for one round, from ONE build, in one GPU-box call:  tools/profile_round.sh r03
 # (run it through gpurun; the summaries land in gpurun_out/prof_<round>_*, the default bench line in
 # gpurun_out/<round>_bench_default.json -- copy both sets into profiles/ afterwards).
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-N=${1:-r02}
+N=${1:-r03}
 cd $R
 WORKLOAD="100000 1920 1080 0" bash tools/profile_all.sh ${N}_sh0 --chunk 32
 WORKLOAD="100000 1920 1080 3" PASSES="trace sq valu fetch write" bash tools/profile_all.sh ${N}_sh3 --sh-degree 3 --chunk 32
@@ -23,4 +23,6 @@ cd $R
 for f in gpurun_out/prof_${N}_*; do cp $f profiles/$(basename $f | sed 's/^prof_//'); done
 python bench.py > gpurun_out/${N}_bench_default.json 2> gpurun_out/${N}_bench_default.err
 python tools/bench_next_rows.py > gpurun_out/prof_${N}_next_rows.md 2> gpurun_out/${N}_next_rows.err || true
+python tools/bench_stylegan_ops.py > gpurun_out/prof_${N}_stylegan_ops.md 2> gpurun_out/${N}_stylegan_ops.err || true
+python tools/isa_audit.py > gpurun_out/prof_${N}_isa_audit.md 2> gpurun_out/${N}_isa_audit.err || true
 tail -c 400 gpurun_out/${N}_bench_default.json
