@@ -117,12 +117,15 @@ def _grad_err(gpu, ref, scale) -> float:
     return float((gpu.detach().cpu().double() - ref.double()).abs().sum() / (scale.double().sum() + 1e-30))
 
 
-# Bounds of the two additional numbers per leaf (measured on MI355X, printed by the tests with -s):
+# Bounds of the two additional numbers per leaf (measured on MI355X, profiles/r03_test_numbers.txt; printed with -s):
 #   strict   = sum |gpu - oracle| / sum |oracle|   with the SAME dL/dimage on both sides (stage-wise inputs); differs from the
-#              asserted stage-wise metric only where the hinge and the photometric part cancel (`_opacity`, `_scaling`)
-#   end2end  = the same ratio against the chain driven by the host oracle's OWN loss gradient (nothing shared but the inputs)
-STRICT_TOL = 1e-4
-END_TO_END_TOL = 5e-4
+#              asserted stage-wise metric only where the hinge and the photometric part cancel (`_opacity`, `_scaling`):
+#              measured <= 6.2e-7 on every leaf of both steps
+#   end2end  = the same ratio against the chain driven by the host oracle's OWN loss gradient (independent L1 / SSIM
+#              implementation; the two chains share only the rasterizer inputs): measured <= 3.8e-6 -- bounded by the north
+#              star's 1e-4 itself
+STRICT_TOL = 1e-5
+END_TO_END_TOL = 1e-4
 
 
 def _report_and_bound(tag, names, gpu, leaves, scale, end_to_end):
