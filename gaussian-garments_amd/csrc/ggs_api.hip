@@ -268,6 +268,8 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
     uint32_t* order = (uint32_t*)(b + L.order);
     uint32_t* bucket_count = (uint32_t*)(b + L.header + GGS_BUCKET_COUNT_OFF);
     uint32_t* bucket_cursor = (uint32_t*)(b + L.header + GGS_BUCKET_CURSOR_OFF);
+    uint32_t* region_count = (uint32_t*)(b + L.header + GGS_REGION_COUNT_OFF);
+    uint32_t* region_cursor = (uint32_t*)(b + L.header + GGS_REGION_CURSOR_OFF);
     const int n_items = V * d.T;
     const size_t HW = (size_t)p->W * p->H;
     float* final_T = (float*)img;
@@ -293,7 +295,7 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
     }
     {
         ScanArgs a;
-        a.T = d.T; a.capacity = (unsigned long long)bin_capacity; a.tile_count = tile_count;
+        a.T = d.T; a.gx = d.gx; a.region_count = region_count; a.capacity = (unsigned long long)bin_capacity; a.tile_count = tile_count;
         a.tile_offset = tile_offset; a.view_base = view_base; a.header = header; a.bucket_count = bucket_count;
         if (V == 1) {             // one view: scan and work-item order in one launch (ggs_k_scan_order_one)
             prof_start(K_SCAN, s);
@@ -308,6 +310,7 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
         OrderArgs o;
         o.n_items = n_items; o.tile_count = tile_count; o.bucket_count = bucket_count;
         o.bucket_cursor = bucket_cursor; o.order = order;
+        o.T = d.T; o.gx = d.gx; o.region_count = region_count; o.region_cursor = region_cursor;
         prof_start(K_ORDER, s);
         hipLaunchKernelGGL(ggs_k_order_tiles, dim3((unsigned)((n_items + 255) / 256)), dim3(256), 0, s, o);
         prof_stop(K_ORDER, s);

@@ -18,8 +18,9 @@ __global__ __launch_bounds__(1024) void ggs_k_scan_tiles(ScanArgs a) {
     uint32_t* off = a.tile_offset + (size_t)v * a.T;
     const int per = (a.T + 1023) / 1024;
     const int t0 = tid * per;
-    __shared__ uint32_t s_bucket[GGS_NBUCKET];
+    __shared__ uint32_t s_bucket[GGS_NBUCKET], s_region[GGS_NBUCKET * GGS_NREGION];
     if (tid < GGS_NBUCKET) s_bucket[tid] = 0;
+    if (tid < GGS_NBUCKET * GGS_NREGION) s_region[tid] = 0;
     __syncthreads();
     // ~90 % of the tiles of an image are empty: counted in a register and added once per wave -- as per-tile LDS
     // atomics on the one "empty" counter they serialised (8160 same-address atomics = most of this kernel's 15 us)
@@ -29,7 +30,11 @@ __global__ __launch_bounds__(1024) void ggs_k_scan_tiles(ScanArgs a) {
             const uint32_t c = cnt[t0 + i];
             local += c;
             if (c == 0) ++n_empty;
-            else atomicAdd(&s_bucket[ggs_len_bucket(c)], 1u);
+            else {
+                const int b = ggs_len_bucket(c);
+                atomicAdd(&s_bucket[b], 1u);
+                atomicAdd(&s_region[b * GGS_NREGION + ggs_tile_region(t0 + i, a.gx)], 1u);
+            }
         }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) n_empty += __shfl_xor(n_empty, d);
@@ -58,12 +63,42 @@ __global__ __launch_bounds__(1024) void ggs_k_scan_tiles(ScanArgs a) {
             run += cnt[t0 + i];
         }
     if (tid < GGS_NBUCKET && s_bucket[tid]) atomicAdd(&a.bucket_count[tid], s_bucket[tid]);
+    if (tid < GGS_NBUCKET * GGS_NREGION && s_region[tid]) atomicAdd(&a.region_count[tid], s_region[tid]);
     if (tid == 0) {
         const unsigned long long base = atomicAdd(&a.header->num_rendered, (unsigned long long)total);
         a.view_base[v] = base;
         if (base + total > a.capacity) atomicExch(&a.header->overflow, 1ull);
     }
 }
+
+namespace {
+// Rank inside its class (0 .. n_c - 1) of the kk-th tile of region g: see ggs_k_order_tiles.  `start` = first non-empty rank of
+// the class, k + 1 = distance of consecutive non-empty ranks in order[] (odd), m[h] = tiles of the class in region h.
+__device__ __forceinline__ uint32_t ggs_region_rank(uint32_t start, uint32_t n_c, uint32_t k, const uint32_t* m, int g, uint32_t kk) {
+    const uint32_t step = (k + 1) & 7u;                       // odd
+    uint32_t inv = 1;                                         // step * inv == 1 (mod 8)
+    for (uint32_t t = 1; t < 8; t += 2) if (((step * t) & 7u) == 1u) inv = t;
+    const uint32_t x0 = (start * step) & 7u;                  // XCD of the class's first rank
+    // ranks of the class on XCD h: first_h + 8 j, j < S_h
+    const uint32_t first = (((uint32_t)g + 8u - x0) * inv) & 7u;
+    const uint32_t S = first < n_c ? (n_c - 1 - first) / 8 + 1 : 0;
+    if (kk < S) return first + 8 * kk;
+    uint32_t o = kk - S;                                      // overflow index inside the region ...
+    for (int h = 0; h < g; ++h) {                             // ... made global over the regions in front
+        const uint32_t fh = (((uint32_t)h + 8u - x0) * inv) & 7u;
+        const uint32_t Sh = fh < n_c ? (n_c - 1 - fh) / 8 + 1 : 0;
+        if (m[h] > Sh) o += m[h] - Sh;
+    }
+    for (int h = 0; h < GGS_NREGION; ++h) {                   // the o-th rank left free by an under-full region
+        const uint32_t fh = (((uint32_t)h + 8u - x0) * inv) & 7u;
+        const uint32_t Sh = fh < n_c ? (n_c - 1 - fh) / 8 + 1 : 0;
+        const uint32_t free_h = Sh > m[h] ? Sh - m[h] : 0;
+        if (o < free_h) return fh + 8 * (m[h] + o);
+        o -= free_h;
+    }
+    return 0;       // not reached: the overflow of the full regions equals the room of the others
+}
+}  // namespace
 
 // K2b: grid ceil(V*T/256), block 256.  Counting sort of the (view, tile) work items by list-length
 // class (longest first) into order[]; inside a class the order is arbitrary.  Empty tiles (class 7:
@@ -72,36 +107,42 @@ __global__ __launch_bounds__(1024) void ggs_k_scan_tiles(ScanArgs a) {
 // with NE non-empty and E empty items and k = E / NE rounded down to even, item slots repeat
 // [1 non-empty, k empty] and the E - k NE left-over empties go last.
 __global__ __launch_bounds__(256) void ggs_k_order_tiles(OrderArgs a) {
-    __shared__ uint32_t s_n[GGS_NBUCKET], s_base[GGS_NBUCKET];
+    // XCD-aware placement inside a class (ggs_tile_region): the class owns the non-empty ranks [start, start + n_c); rank r sits
+    // at order[r (k + 1)], i.e. on XCD (r (k + 1)) % 8 -- k + 1 is odd, so the XCDs of consecutive ranks cycle through all 8 with
+    // a fixed step.  Region g of the class gets the ranks whose XCD is g, in arrival order; what does not fit (the class holds
+    // more tiles of g than an eighth of its ranks) takes the ranks the under-full regions leave free, through a fixed
+    // (prefix-sum) assignment: a bijection, no second pass.
+    __shared__ uint32_t s_n[GGS_NBUCKET * GGS_NREGION], s_base[GGS_NBUCKET * GGS_NREGION], s_ne[1], s_nb[1];
     const int tid = threadIdx.x;
     const int i = blockIdx.x * 256 + tid;
-    if (tid < GGS_NBUCKET) s_n[tid] = 0;
+    if (tid < GGS_NBUCKET * GGS_NREGION) s_n[tid] = 0;
+    if (tid == 0) { s_ne[0] = 0; }
     __syncthreads();
-    int b = 0;
+    int b = 0, g = 0;
     uint32_t rank = 0;
     if (i < a.n_items) {
         b = ggs_len_bucket(a.tile_count[i]);
-        rank = atomicAdd(&s_n[b], 1u);
+        g = b == GGS_NBUCKET - 1 ? 0 : ggs_tile_region(i % a.T, a.gx);
+        rank = atomicAdd(&s_n[b * GGS_NREGION + g], 1u);
     }
     __syncthreads();
-    if (tid < GGS_NBUCKET) {
-        uint32_t start = 0;                       // rank of the class among the non-empty items (class 7: 0)
-        if (tid < GGS_NBUCKET - 1)
-            for (int k = 0; k < tid; ++k) start += a.bucket_count[k];
-        s_base[tid] = s_n[tid] ? start + atomicAdd(&a.bucket_cursor[tid], s_n[tid]) : 0;
-    }
+    if (tid < GGS_NBUCKET * GGS_NREGION) s_base[tid] = s_n[tid] ? atomicAdd(&a.region_cursor[tid], s_n[tid]) : 0;
     __syncthreads();
+    (void)s_nb;
     if (i < a.n_items) {
         const uint32_t E = a.bucket_count[GGS_NBUCKET - 1];
         const uint32_t NE = (uint32_t)a.n_items - E;
         // k even => period k + 1 odd: workgroup b lands on XCD b % 8 (observed), so an even period would
         // park all the non-empty tiles on a subset of the 8 XCDs
         const uint32_t k = NE ? (E / NE) & ~1u : 0;
-        const uint32_t r = s_base[b] + rank;      // rank among non-empty items, or among the empty ones
+        const uint32_t kk = s_base[b * GGS_NREGION + g] + rank;      // index inside (class, region); class 15: among the empties
         uint32_t pos;
-        if (b != GGS_NBUCKET - 1) pos = r * (k + 1);
-        else if (r < k * NE) pos = (r / k) * (k + 1) + 1 + (r % k);
-        else pos = NE * (k + 1) + (r - k * NE);
+        if (b != GGS_NBUCKET - 1) {
+            uint32_t start = 0;
+            for (int c = 0; c < b; ++c) start += a.bucket_count[c];
+            pos = (start + ggs_region_rank(start, a.bucket_count[b], k, a.region_count + b * GGS_NREGION, g, kk)) * (k + 1);
+        } else if (kk < k * NE) pos = (kk / k) * (k + 1) + 1 + (kk % k);
+        else pos = NE * (k + 1) + (kk - k * NE);
         a.order[pos] = (uint32_t)i;
     }
 }
@@ -110,7 +151,8 @@ __global__ __launch_bounds__(256) void ggs_k_order_tiles(OrderArgs a) {
 // holds the complete list-length class histogram in LDS, so it places the work items right away -- a single-view iteration
 // is a chain of latency-bound launches and this removes one kernel boundary and the second pass over
 // tile_count.  Same order[] layout as ggs_k_order_tiles (non-empty items longest class first at r * (k + 1), empties
-// interleaved); inside a class the order is arbitrary there and here.
+// interleaved); inside a class the order is arbitrary (the XCD-aware placement of ggs_k_order_tiles measured no
+// gain for a single view: 2.19k against 2.21k iterations / s).
 __global__ __launch_bounds__(1024) void ggs_k_scan_order_one(ScanArgs a, uint32_t* order) {
     const int tid = threadIdx.x;
     const uint32_t* cnt = a.tile_count;

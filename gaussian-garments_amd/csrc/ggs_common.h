@@ -30,6 +30,11 @@
 #define GGS_NBUCKET 16            // list-length classes used to order the per-tile work items
 #define GGS_BUCKET_COUNT_OFF 64   // byte offsets inside the header region
 #define GGS_BUCKET_CURSOR_OFF 128
+// XCD-aware work order (ggs_k_order_tiles): the same histogram and cursors per (list-length class, XCD region of the tile)
+#define GGS_NREGION 8
+#define GGS_REGION_COUNT_OFF 256      // [GGS_NBUCKET][GGS_NREGION] u32
+#define GGS_REGION_CURSOR_OFF 768     // [GGS_NBUCKET][GGS_NREGION] u32
+#define GGS_HEADER_BYTES 2048
 
 // Constants of the algorithm, one line each.
 #define GGS_NEAR_Z 0.2f
@@ -88,7 +93,7 @@ static inline size_t ggs_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline BinLayout ggs_bin_layout(int V, int T, size_t cap) {
     BinLayout L;
     size_t o = 0;
-    L.header = o;      o += ggs_align(sizeof(GgsBinHeader));
+    L.header = o;      o += GGS_HEADER_BYTES;
     L.tile_count = o;  o += ggs_align((size_t)V * T * 4);
     L.tile_cursor = o; o += ggs_align((size_t)V * T * 4);
     L.zero_bytes = o;
@@ -119,6 +124,15 @@ __device__ __forceinline__ int ggs_len_bucket(uint32_t L) {
     if (lg == 5) return 12;
     const int half = (int)((L >> (lg - 1)) & 1u);          // second most significant bit
     return 2 * (11 - lg) + (1 - half);
+}
+
+// XCD region of a tile.  Workgroup b of a launch runs on XCD b % 8 (observed), every XCD has its own L2, and a splat's record
+// is gathered by every tile it touches: blocks of 4 x 4 tiles (64 x 64 px -- a splat's tiles almost always lie inside one) are
+// dealt round-robin to the 8 regions, and ggs_k_order_tiles places a tile of region g at a work-item position whose XCD is g
+// wherever the class sizes allow, so that the tiles sharing a record share an L2.
+__device__ __forceinline__ int ggs_tile_region(int t, int gx) {
+    const int tx = t % gx, ty = t / gx;
+    return ((tx >> 2) + (ty >> 2) * ((gx + 3) >> 2)) & (GGS_NREGION - 1);
 }
 
 // Position in order[] of the r-th non-empty work item (longest first); mirrors ggs_k_order_tiles.

@@ -14,7 +14,8 @@ struct PreArgs {
 };
 
 struct ScanArgs {
-    int T;
+    int T, gx;
+    uint32_t* region_count;   // [GGS_NBUCKET][GGS_NREGION]
     unsigned long long capacity;
     const uint32_t* tile_count;
     uint32_t* tile_offset;
@@ -25,6 +26,9 @@ struct ScanArgs {
 
 struct OrderArgs {
     int n_items;              // V * T
+    int T, gx;
+    const uint32_t* region_count;     // [GGS_NBUCKET][GGS_NREGION]
+    uint32_t* region_cursor;          // [GGS_NBUCKET][GGS_NREGION]
     const uint32_t* tile_count;
     const uint32_t* bucket_count;
     uint32_t* bucket_cursor;

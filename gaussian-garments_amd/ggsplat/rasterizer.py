@@ -276,7 +276,9 @@ def bin_sections(st: ForwardState) -> Dict[str, torch.Tensor]:
 
     return dict(header=sec(0, 16, torch.int64), tile_count=sec(1, V * T * 4, torch.int32).reshape(V, T),
                 tile_offset=sec(3, V * T * 4, torch.int32).reshape(V, T), view_base=sec(4, V * 8, torch.int64),
-                keys=sec(5, st.cap * 8, torch.int64), ids=sec(6, st.cap * 4, torch.int32))
+                keys=sec(5, st.cap * 8, torch.int64), ids=sec(6, st.cap * 4, torch.int32),
+                # work items in launch order: behind view_base (256-byte aligned sections, csrc/ggs_common.h ggs_bin_layout)
+                order=b[off[4] + ((V * 8 + 255) & ~255):off[4] + ((V * 8 + 255) & ~255) + V * T * 4].view(torch.int32))
 
 
 def img_sections(st: ForwardState) -> Dict[str, torch.Tensor]:

@@ -262,3 +262,45 @@ def test_stress_config_view_against_the_c_oracle():
     for k in ("means3D", "opacities", "shs", "scales", "rotations"):
         assert rel_l1(gr[k].cpu().reshape(og[k].shape), og[k]) <= REL_L1_TOL, k
     co.close()
+
+
+def test_work_order_is_a_permutation_and_xcd_aware(scene):
+    """order[] of an eight-view launch (ggs_k_order_tiles): every (view, tile) item exactly once; the non-empty items sit at
+    positions r * stride in list-length class order (longest lists first); and the placement is XCD-aware -- workgroup b runs
+    on XCD b % 8, each XCD has its own L2, and the tiles of one 4 x 4 block (which share their splats' records) land on the XCD
+    of their region wherever the class sizes allow: most non-empty items sit at a position p with p % 8 == region(tile)."""
+    import numpy as np
+    from ggsplat import rasterizer as R
+    inp, _ = scene
+    P = inp["means3D"].shape[0]
+    shs = torch.zeros(P, 1, 3, device="cuda")
+    cams = [S.rig_cameras()[i] for i in (3, 30, 41, 77, 90, 118, 133, 158)]
+    ck = S.stack_cameras(cams, device="cuda")
+    *_, st = R.forward_views(inp["means3D"], inp["opacities"], shs, None, inp["scales"], inp["rotations"], None, view=ck["view"],
+                             proj=ck["proj"], campos=ck["campos"], tanfov=ck["tanfov"], bg=torch.zeros(3, device="cuda"), W=W, H=H,
+                             sh_degree=0)
+    V, gx, gy = 8, (W + 15) // 16, (H + 15) // 16
+    T = gx * gy
+    sec = R.bin_sections(st)
+    order = sec["order"].cpu().numpy().astype(np.int64)
+    cnt = sec["tile_count"].reshape(-1).cpu().numpy().astype(np.int64)
+    assert np.array_equal(np.sort(order), np.arange(V * T))
+    ne = cnt > 0
+    NE, E = int(ne.sum()), int((~ne).sum())
+    stride = ((E // NE) & ~1) + 1
+    pos_ne = np.arange(NE) * stride
+    items = order[pos_ne]
+    assert ne[items].all() and not ne[np.setdiff1d(order, items)].any()
+
+    def bucket(L):
+        lg = int(L).bit_length() - 1
+        if lg >= 12: return 0
+        if lg <= 4: return 13
+        if lg == 5: return 12
+        return 2 * (11 - lg) + (1 - ((L >> (lg - 1)) & 1))
+    classes = np.array([bucket(c) for c in cnt[items]])
+    assert (np.diff(classes) >= 0).all()                                   # longest lists first
+    t = items % T
+    region = ((t % gx) // 4 + (t // gx) // 4 * ((gx + 3) // 4)) % 8
+    frac = float((pos_ne % 8 == region).mean())
+    assert frac > 0.7, frac
