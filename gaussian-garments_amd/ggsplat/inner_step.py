@@ -175,17 +175,20 @@ class GraphedRegistrationStep:
         """The 37 floats of a camera (matrices, centre, tangents) as a host tensor, packed once per camera object (the
         reference's Camera keeps its matrices on the GPU, scene/cameras.py:59-62: one read-back each, at first use)."""
         import math
+        mats = (cam.world_view_transform, cam.full_proj_transform, cam.camera_center)
+        vers = tuple(getattr(m, "_version", 0) for m in mats) + (float(cam.FoVx), float(cam.FoVy))
         ent = self._cam_cache.get(id(cam))
-        if ent is not None and ent[0] is cam:
+        if ent is not None and ent[0] is cam and ent[2] == vers and all(a is b for a, b in zip(ent[3], mats)):
             return ent[1]
         t = torch.zeros(40)
-        t[0:16] = cam.world_view_transform.detach().reshape(16).float().cpu()
-        t[16:32] = cam.full_proj_transform.detach().reshape(16).float().cpu()
-        t[32:35] = cam.camera_center.detach().reshape(3).float().cpu()
+        t[0:16] = mats[0].detach().reshape(16).float().cpu()
+        t[16:32] = mats[1].detach().reshape(16).float().cpu()
+        t[32:35] = mats[2].detach().reshape(3).float().cpu()
         t[35], t[36] = math.tan(cam.FoVx * 0.5), math.tan(cam.FoVy * 0.5)
         if len(self._cam_cache) > 4096:
             self._cam_cache.clear()
-        self._cam_cache[id(cam)] = (cam, t)
+        # the entry holds the camera and its tensors (no id() reuse) and their version counters (an in-place edit re-packs)
+        self._cam_cache[id(cam)] = (cam, t, vers, mats)
         return t
 
     def _resident(self, t, landing, shape):

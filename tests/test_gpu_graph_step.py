@@ -236,3 +236,34 @@ def test_graphed_appearance_step_matches_eager_gather_semantics():
     close(ng.sh_off.detach(), ne.sh_off.detach(), "net.sh_off")
     close(mg._opacity.detach(), me._opacity.detach(), "_opacity")
     close(mg._scaling.detach(), me._scaling.detach(), "_scaling")
+
+
+def test_graphed_step_takes_host_images_and_follows_camera_edits():
+    """What changes per iteration reaches a replay through ONE small device block: camera matrices (packed once per camera
+    object) and the device addresses of ground truth / mask.  (1) Images that live on the HOST go through the landing buffers
+    and give the same losses as the same images on the GPU; (2) a camera whose matrices are edited IN PLACE is re-packed (the
+    cache follows the tensors' version counters), so the next replay renders the new view."""
+    from ggsplat.inner_step import DEFAULT_OPT, GraphedRegistrationStep
+    v, f, params, cams, gts, masks = _scene(3)
+    opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "position_lr_init": 0.0, "feature_lr": 0.0, "opacity_lr": 0.0,
+                             "scaling_lr": 0.0, "rotation_lr": 0.0})      # frozen parameters: the losses depend on the inputs only
+    bg = torch.zeros(3, device="cuda")
+    m = _model(v, f, params, opt, graph=True)
+    for grp in m.optimizer.param_groups:
+        grp["lr"] = 0.0
+    m.optimizer.push_lr()
+    step = GraphedRegistrationStep(m, W, H, bg, opt=opt)
+    on_gpu = step(cams[0], gts[0], masks[0])
+    on_host = step(cams[0], gts[0].cpu(), masks[0].cpu())
+    assert abs(on_gpu["loss"] - on_host["loss"]) <= 1e-6 * abs(on_gpu["loss"])
+    other = step(cams[1], gts[0], masks[0])
+    assert abs(other["img"] - on_gpu["img"]) > 1e-4                      # another camera, another image
+    saved = [getattr(cams[0], n).clone() for n in ("world_view_transform", "full_proj_transform", "camera_center")]
+    for n in ("world_view_transform", "full_proj_transform", "camera_center"):
+        getattr(cams[0], n).copy_(getattr(cams[1], n))                    # in place: same tensor objects, new versions
+    cams[0].FoVx, cams[0].FoVy = cams[1].FoVx, cams[1].FoVy
+    edited = step(cams[0], gts[0], masks[0])
+    assert abs(edited["loss"] - other["loss"]) <= 1e-6 * abs(other["loss"])
+    for n, t in zip(("world_view_transform", "full_proj_transform", "camera_center"), saved):
+        getattr(cams[0], n).copy_(t)
+    assert step.recaptures == 0
