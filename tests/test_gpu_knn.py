@@ -97,3 +97,21 @@ def test_world_frame_ply_holds_the_getters(tmp_path):
     assert torch.equal(d["_scaling"], torch.log(m.get_scaling).detach().cpu()[keep])
     assert torch.equal(d["_rotation"], m.get_rotation.detach().cpu()[keep])
     assert not (tmp_path / "point_cloud" / "frame_00003" / "binding.pkl").exists()
+
+
+@pytest.mark.parametrize("P", [1, 3, 4, 5, 40])
+def test_grid_entry_point_with_very_few_points(P):
+    """ggs_dist2_3nn_grid called directly (the shim sends fewer than 64 points to the brute force): same bits as the brute
+    force, missing neighbours counted as FLT_MAX like upstream."""
+    import ctypes as C
+    from ggsplat._lib import check, lib, ptr
+    pts = torch.randn(P, 3, generator=torch.Generator().manual_seed(P)).cuda()
+    L = lib()
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    a, b = torch.empty(P, device="cuda"), torch.empty(P, device="cuda")
+    scratch = torch.empty(L.ggs_dist2_3nn_scratch_bytes(P), device="cuda", dtype=torch.uint8)
+    check(L.ggs_dist2_3nn_grid(P, ptr(pts), ptr(a), ptr(scratch), stream), "grid")
+    check(L.ggs_dist2_3nn(P, ptr(pts), ptr(b), stream), "brute")
+    assert torch.equal(a, b)
+    if P < 4:
+        assert float(a.min()) > 1e37
