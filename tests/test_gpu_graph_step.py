@@ -267,3 +267,43 @@ def test_graphed_step_takes_host_images_and_follows_camera_edits():
     for n, t in zip(("world_view_transform", "full_proj_transform", "camera_center"), saved):
         getattr(cams[0], n).copy_(t)
     assert step.recaptures == 0
+
+
+def test_graphed_appearance_step_with_a_convolutional_net():
+    """The captured s3 iteration with a NETWORK producing the offsets (what bench.py's `config4_s3_with_network` line times):
+    ggsplat.stylenet.StyleUNetLite on the HIP fused_bias_act / upfirdn2d ops + PyTorch convolutions inside the hipGraph, sampled
+    at per-Gaussian UV coordinates.  Replays against the eager appearance_step with torch.optim.Adam on a twin."""
+    import copy
+    from ggsplat.adam import GraphAdam
+    from ggsplat.inner_step import DEFAULT_OPT, GraphedAppearanceStep, appearance_step
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    from ggsplat.stylenet import CHANNELS, StyleUNetLite, TexelOffsets
+    opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "threshold_xyz": 0.05, "threshold_scale": 0.02})
+    v, f, params, cams, gts, masks = _scene(seed=6)
+    P = f.shape[0]
+    bg = torch.zeros(3, device="cuda")
+    g = torch.Generator().manual_seed(21)
+    uv, vis = torch.rand(P, 2, generator=g).cuda(), (torch.rand(P, generator=g) > 0.3).cuda()
+    cond = torch.randn(1, 4, 64, 64, generator=g).cuda()
+    torch.manual_seed(22)
+    unet = StyleUNetLite(size=64, in_ch=4, out_ch=6, style_dim=32, impl="hip", channels={k: min(c, 16) for k, c in CHANNELS.items()})
+    net_g = TexelOffsets(unet, uv, 1, vis, cond).cuda()
+    net_e = copy.deepcopy(net_g)
+    sides = []
+    for net, graph in ((net_e, False), (net_g, True)):
+        m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
+        groups = [{"params": list(net.parameters()), "lr": 1e-3, "name": "net"}, {"params": [m._opacity], "lr": 1e-2, "name": "opacity"}]
+        o = GraphAdam(groups, lr=0.0, eps=1e-15) if graph else torch.optim.Adam(groups, lr=0.0, eps=1e-15)
+        sides.append((m, o))
+    (me, oe), (mg, og) = sides
+    step = GraphedAppearanceStep(mg, net_g, W, H, bg, og, opt=opt)
+    for ci in (0, 2, 4):
+        ref = appearance_step(me, net_e, cams[ci], gts[ci], masks[ci], bg, optimizer=oe, opt=opt, fused_loss=True)
+        out = step(cams[ci], gts[ci], masks[ci])
+        for k in ("img", "ssim", "loss"):
+            r = float(ref[k].detach())
+            assert abs(float(out[k]) - r) <= 2e-4 * max(1.0, abs(r)), (ci, k, float(out[k]), r)
+    assert step.recaptures == 0 and og.step_count == 3
+    # the two nets trained in step: the style mapping's first layer after three Adam steps
+    wg, we = net_g.net.mapping[0].weight.detach(), net_e.net.mapping[0].weight.detach()
+    assert float((wg - we).abs().mean()) <= 5e-4 * float(we.abs().mean()) + 1e-7
