@@ -39,6 +39,20 @@ template <> __device__ __forceinline__ float ld<__half>(const __half* p) { retur
 template <typename T, typename A> __device__ __forceinline__ void st(T* p, A v) { *p = (T)v; }
 template <> __device__ __forceinline__ void st<__half, float>(__half* p, float v) { *p = __float2half(v); }
 
+// two adjacent elements as one access (half: 4 bytes, float: 8 bytes); the address is a multiple of 2 elements
+template <typename T, typename A> __device__ __forceinline__ void ld2(const T* p, A& v0, A& v1) { v0 = ld(p); v1 = ld(p + 1); }
+template <> __device__ __forceinline__ void ld2<__half, float>(const __half* p, float& v0, float& v1) {
+    const __half2 h2 = *reinterpret_cast<const __half2*>(p);
+    v0 = __low2float(h2); v1 = __high2float(h2);
+}
+template <> __device__ __forceinline__ void ld2<float, float>(const float* p, float& v0, float& v1) {
+    const float2 f2 = *reinterpret_cast<const float2*>(p);
+    v0 = f2.x; v1 = f2.y;
+}
+template <typename T, typename A> __device__ __forceinline__ void st2(T* p, A v0, A v1) { st(p, v0); st(p + 1, v1); }
+template <> __device__ __forceinline__ void st2<__half, float>(__half* p, float v0, float v1) { *reinterpret_cast<__half2*>(p) = __floats2half2_rn(v0, v1); }
+template <> __device__ __forceinline__ void st2<float, float>(float* p, float v0, float v1) { *reinterpret_cast<float2*>(p) = make_float2(v0, v1); }
+
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T>
 struct BiasActArgs {
@@ -175,7 +189,7 @@ __device__ __forceinline__ void ufd_rows(const A* __restrict__ base, const A (&w
     }
 }
 
-// VEC (half only, even in_w): the patch is staged in pairs of input columns, one 4-byte load each.
+// VEC (half / float, even in_w): the patch is staged in pairs of input columns, one 4- / 8-byte load each.
 template <typename T, int UP, int DOWN, int KH, int KW, int COLS, bool VEC>
 __global__ __launch_bounds__(256) void k_upfirdn2d_tile(UpfirdnArgs<T> a) {
     typedef typename Acc<T>::type A;
@@ -196,8 +210,7 @@ __global__ __launch_bounds__(256) void k_upfirdn2d_tile(UpfirdnArgs<T> a) {
             const int ix = ix_lo + c, iy = iy_lo + r;
             A v0 = (A)0, v1 = (A)0;
             if (ix >= 0 && ix < a.in_w && iy >= 0 && iy < a.in_h) {
-                const __half2 h2 = *reinterpret_cast<const __half2*>(src + (size_t)iy * a.in_w + ix);
-                v0 = __low2float(h2); v1 = __high2float(h2);
+                ld2<T, A>(src + (size_t)iy * a.in_w + ix, v0, v1);
             }
             patch[r * LD + c] = v0;
             if (c + 1 < PW) patch[r * LD + c + 1] = v1;
@@ -247,7 +260,7 @@ __global__ __launch_bounds__(256) void k_upfirdn2d_tile(UpfirdnArgs<T> a) {
         for (int r = 0; r < 4; ++r) {
             if (oyb + r >= a.out_h) break;
             if constexpr (COLS == 2) {                       // out_w is even (launch condition): ox + 1 < out_w, 4-byte aligned
-                *reinterpret_cast<__half2*>(dst + (size_t)(oyb + r) * a.out_w) = __floats2half2_rn(acc[0][r], acc[1][r]);
+                st2<T, A>(dst + (size_t)(oyb + r) * a.out_w, acc[0][r], acc[1][r]);
             } else {
                 st(dst + (size_t)(oyb + r) * a.out_w, acc[0][r]);
             }
@@ -261,14 +274,15 @@ int launch_upfirdn(const UpfirdnArgs<T>& a, hipStream_t s) {
     const bool sq = a.up_x == a.up_y && a.down_x == a.down_y && a.kh == a.kw && a.minor == 1 && a.major <= 65535;
     typedef typename Acc<T>::type A;
     const int key = sq && a.out_h / 16 + 1 <= 65535 ? a.up_x * 100 + a.down_x * 10 + a.kh : -1;
-    // half: 4-byte accesses need even row pitches, even plane sizes and 4-byte aligned bases
-    const bool vec_in = sizeof(T) == 2 && (a.in_w & 1) == 0 && (reinterpret_cast<uintptr_t>(a.in) & 3) == 0 && (((size_t)a.in_h * a.in_w) & 1) == 0;
-    const bool vec_out = sizeof(T) == 2 && (a.out_w & 1) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 3) == 0 && (((size_t)a.out_h * a.out_w) & 1) == 0;
+    // pair accesses (half: 4 bytes, float: 8) need even row pitches, even plane sizes and aligned bases
+    constexpr uintptr_t PAIR_ALIGN = 2 * sizeof(T) - 1;
+    const bool vec_in = sizeof(T) <= 4 && (a.in_w & 1) == 0 && (reinterpret_cast<uintptr_t>(a.in) & PAIR_ALIGN) == 0 && (((size_t)a.in_h * a.in_w) & 1) == 0;
+    const bool vec_out = sizeof(T) <= 4 && (a.out_w & 1) == 0 && (reinterpret_cast<uintptr_t>(a.out) & PAIR_ALIGN) == 0 && (((size_t)a.out_h * a.out_w) & 1) == 0;
     (void)vec_in; (void)vec_out;
     switch (key) {
 #define UFD_CASE(UP, DOWN, K) \
         case UP * 100 + DOWN * 10 + K: {                                                                                         \
-            if constexpr (sizeof(T) == 2) {                                                                                       \
+            if constexpr (sizeof(T) <= 4) {       /* half and float: pair accesses */                                             \
                 /* half: two output columns per lane (up-sampling and same-size filters; a down-sampling tile of 128 columns  */ \
                 /* needs a 36 KB patch and measured slower) or at least the column-pair staging                                */ \
                 if (vec_in && vec_out && DOWN == 1) {                                                                             \
