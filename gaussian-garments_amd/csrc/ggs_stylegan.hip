@@ -39,19 +39,38 @@ template <> __device__ __forceinline__ float ld<__half>(const __half* p) { retur
 template <typename T, typename A> __device__ __forceinline__ void st(T* p, A v) { *p = (T)v; }
 template <> __device__ __forceinline__ void st<__half, float>(__half* p, float v) { *p = __float2half(v); }
 
-// two adjacent elements as one access (half: 4 bytes, float: 8 bytes); the address is a multiple of 2 elements
-template <typename T, typename A> __device__ __forceinline__ void ld2(const T* p, A& v0, A& v1) { v0 = ld(p); v1 = ld(p + 1); }
-template <> __device__ __forceinline__ void ld2<__half, float>(const __half* p, float& v0, float& v1) {
-    const __half2 h2 = *reinterpret_cast<const __half2*>(p);
-    v0 = __low2float(h2); v1 = __high2float(h2);
-}
-template <> __device__ __forceinline__ void ld2<float, float>(const float* p, float& v0, float& v1) {
-    const float2 f2 = *reinterpret_cast<const float2*>(p);
-    v0 = f2.x; v1 = f2.y;
-}
-template <typename T, typename A> __device__ __forceinline__ void st2(T* p, A v0, A v1) { st(p, v0); st(p + 1, v1); }
-template <> __device__ __forceinline__ void st2<__half, float>(__half* p, float v0, float v1) { *reinterpret_cast<__half2*>(p) = __floats2half2_rn(v0, v1); }
-template <> __device__ __forceinline__ void st2<float, float>(float* p, float v0, float v1) { *reinterpret_cast<float2*>(p) = make_float2(v0, v1); }
+// VW adjacent elements as ONE access of up to 8 bytes (float: 2, half: 2 or 4); the address is a multiple of VW elements
+template <typename T, typename A, int VW> struct VecIO {
+    static __device__ __forceinline__ void load(const T* p, A (&v)[VW]) {
+#pragma unroll
+        for (int k = 0; k < VW; ++k) v[k] = ld(p + k);
+    }
+    static __device__ __forceinline__ void store(T* p, const A (&v)[VW]) {
+#pragma unroll
+        for (int k = 0; k < VW; ++k) st(p + k, v[k]);
+    }
+};
+template <> struct VecIO<float, float, 2> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[2]) { const float2 f = *reinterpret_cast<const float2*>(p); v[0] = f.x; v[1] = f.y; }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[2]) { *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]); }
+};
+template <> struct VecIO<__half, float, 2> {
+    static __device__ __forceinline__ void load(const __half* p, float (&v)[2]) { const __half2 h = *reinterpret_cast<const __half2*>(p); v[0] = __low2float(h); v[1] = __high2float(h); }
+    static __device__ __forceinline__ void store(__half* p, const float (&v)[2]) { *reinterpret_cast<__half2*>(p) = __floats2half2_rn(v[0], v[1]); }
+};
+template <> struct VecIO<__half, float, 4> {
+    static __device__ __forceinline__ void load(const __half* p, float (&v)[4]) {
+        const uint2 u = *reinterpret_cast<const uint2*>(p);
+        const __half2 a = *reinterpret_cast<const __half2*>(&u.x), b = *reinterpret_cast<const __half2*>(&u.y);
+        v[0] = __low2float(a); v[1] = __high2float(a); v[2] = __low2float(b); v[3] = __high2float(b);
+    }
+    static __device__ __forceinline__ void store(__half* p, const float (&v)[4]) {
+        const __half2 a = __floats2half2_rn(v[0], v[1]), b = __floats2half2_rn(v[2], v[3]);
+        uint2 u;
+        u.x = *reinterpret_cast<const unsigned*>(&a); u.y = *reinterpret_cast<const unsigned*>(&b);
+        *reinterpret_cast<uint2*>(p) = u;
+    }
+};
 
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T>
@@ -156,8 +175,8 @@ __global__ __launch_bounds__(256) void k_upfirdn2d(UpfirdnArgs<T> a) {
 // COLS = output columns per lane: 1, or 2 for half (a 128-column tile: the two outputs leave as ONE 4-byte store and the
 // patch is staged with 4-byte loads -- a half tile of 64 columns keeps half the bytes in flight per workgroup that a float
 // tile does, and the kernel is bound by exactly that: 2.0 against 3.0 TB/s for the same op in round 2).
-template <typename A, int UP, int DOWN, int K, int COLS, bool VEC = (COLS == 2)> struct UfdTile {
-    static constexpr int W = ((UFD_TW * COLS - 1) * DOWN + K - 1) / UP + 2 + (VEC ? 1 : 0);     // (+1: a patch staged in column pairs starts on an even input column)
+template <typename A, int UP, int DOWN, int K, int COLS, int VW> struct UfdTile {
+    static constexpr int W = ((UFD_TW * COLS - 1) * DOWN + K - 1) / UP + 2 + (VW - 1);          // (+VW-1: a patch staged VW columns at a time starts on a multiple of VW)
     static constexpr int H32 = ((32 - 1) * DOWN + K - 1) / UP + 2;
     static constexpr int TH = (size_t)H32 * (W + 1) * sizeof(A) <= 16 * 1024 ? 32 : 16;      // measured: the 35 KB patches of down = 2 lose more in occupancy (3.2 -> 1.9 TB/s) than the shorter halo gains
     static constexpr int H = ((TH - 1) * DOWN + K - 1) / UP + 2;
@@ -189,31 +208,33 @@ __device__ __forceinline__ void ufd_rows(const A* __restrict__ base, const A (&w
     }
 }
 
-// VEC (half / float, even in_w): the patch is staged in pairs of input columns, one 4- / 8-byte load each.
-template <typename T, int UP, int DOWN, int KH, int KW, int COLS, bool VEC>
+// VW > 1 (half / float, in_w a multiple of VW): the patch is staged VW input columns per access (4 or 8 bytes).
+template <typename T, int UP, int DOWN, int KH, int KW, int COLS, int VW>
 __global__ __launch_bounds__(256) void k_upfirdn2d_tile(UpfirdnArgs<T> a) {
     typedef typename Acc<T>::type A;
-    typedef UfdTile<A, UP, DOWN, KH, COLS, VEC> Tile;
+    typedef UfdTile<A, UP, DOWN, KH, COLS, VW> Tile;
+    constexpr bool VEC = VW > 1;
     constexpr int PW = Tile::W, PH = Tile::H, LD = PW + 1, TH = Tile::TH, G = TH / 16;      // G groups of 4 rows per lane
     constexpr int TW = UFD_TW * COLS;
     __shared__ A patch[PH * LD];
     const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH, m = blockIdx.z;
     const int px_lo = ox0 * DOWN - a.pad_x0, py_lo = oy0 * DOWN - a.pad_y0;
-    const int ix_lo = VEC ? (ceil_div_up(px_lo, UP) & ~1) : ceil_div_up(px_lo, UP), iy_lo = ceil_div_up(py_lo, UP);
+    const int ix_lo = VEC ? (ceil_div_up(px_lo, UP) & ~(VW - 1)) : ceil_div_up(px_lo, UP), iy_lo = ceil_div_up(py_lo, UP);
     const T* src = a.in + (size_t)m * a.in_h * a.in_w;
     if constexpr (VEC) {
-        // pairs of input columns (even, odd) as one 4-byte load: in_w is even (launch condition), so a pair is inside the
-        // image or outside it as a whole and every pair is 4-byte aligned
-        constexpr int PW2 = (PW + 1) / 2;
-        for (int i = threadIdx.x; i < PW2 * PH; i += 256) {
-            const int r = i / PW2, c = 2 * (i - r * PW2);
+        // groups of VW input columns as one load: in_w is a multiple of VW (launch condition), so a group is inside the image or
+        // outside it as a whole, and every group is aligned
+        constexpr int PWV = (PW + VW - 1) / VW;
+        for (int i = threadIdx.x; i < PWV * PH; i += 256) {
+            const int r = i / PWV, c = VW * (i - r * PWV);
             const int ix = ix_lo + c, iy = iy_lo + r;
-            A v0 = (A)0, v1 = (A)0;
-            if (ix >= 0 && ix < a.in_w && iy >= 0 && iy < a.in_h) {
-                ld2<T, A>(src + (size_t)iy * a.in_w + ix, v0, v1);
-            }
-            patch[r * LD + c] = v0;
-            if (c + 1 < PW) patch[r * LD + c + 1] = v1;
+            A v[VW];
+#pragma unroll
+            for (int k = 0; k < VW; ++k) v[k] = (A)0;
+            if (ix >= 0 && ix < a.in_w && iy >= 0 && iy < a.in_h) VecIO<T, A, VW>::load(src + (size_t)iy * a.in_w + ix, v);
+#pragma unroll
+            for (int k = 0; k < VW; ++k)
+                if (c + k < PW) patch[r * LD + c + k] = v[k];
         }
     } else {
         for (int i = threadIdx.x; i < PW * PH; i += 256) {
@@ -259,8 +280,11 @@ __global__ __launch_bounds__(256) void k_upfirdn2d_tile(UpfirdnArgs<T> a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             if (oyb + r >= a.out_h) break;
-            if constexpr (COLS == 2) {                       // out_w is even (launch condition): ox + 1 < out_w, 4-byte aligned
-                st2<T, A>(dst + (size_t)(oyb + r) * a.out_w, acc[0][r], acc[1][r]);
+            if constexpr (COLS > 1) {                        // out_w is a multiple of COLS (launch condition): one aligned store
+                A o[COLS];
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) o[c] = acc[c][r];
+                VecIO<T, A, COLS>::store(dst + (size_t)(oyb + r) * a.out_w, o);
             } else {
                 st(dst + (size_t)(oyb + r) * a.out_w, acc[0][r]);
             }
@@ -274,38 +298,44 @@ int launch_upfirdn(const UpfirdnArgs<T>& a, hipStream_t s) {
     const bool sq = a.up_x == a.up_y && a.down_x == a.down_y && a.kh == a.kw && a.minor == 1 && a.major <= 65535;
     typedef typename Acc<T>::type A;
     const int key = sq && a.out_h / 16 + 1 <= 65535 ? a.up_x * 100 + a.down_x * 10 + a.kh : -1;
-    // pair accesses (half: 4 bytes, float: 8) need even row pitches, even plane sizes and aligned bases
-    constexpr uintptr_t PAIR_ALIGN = 2 * sizeof(T) - 1;
-    const bool vec_in = sizeof(T) <= 4 && (a.in_w & 1) == 0 && (reinterpret_cast<uintptr_t>(a.in) & PAIR_ALIGN) == 0 && (((size_t)a.in_h * a.in_w) & 1) == 0;
-    const bool vec_out = sizeof(T) <= 4 && (a.out_w & 1) == 0 && (reinterpret_cast<uintptr_t>(a.out) & PAIR_ALIGN) == 0 && (((size_t)a.out_h * a.out_w) & 1) == 0;
-    (void)vec_in; (void)vec_out;
+    // vector accesses of n elements need row pitches and plane sizes that are multiples of n and n-element aligned bases:
+    // in_al / out_al = the largest such n in {1, 2, 4}
+    auto align_of = [](const void* base, int w, size_t plane) {
+        int n = 1;
+        for (int c : {2, 4})
+            if (w % c == 0 && plane % c == 0 && (reinterpret_cast<uintptr_t>(base) % (c * sizeof(T))) == 0) n = c;
+        return n;
+    };
+    const int in_al = align_of(a.in, a.in_w, (size_t)a.in_h * a.in_w), out_al = align_of(a.out, a.out_w, (size_t)a.out_h * a.out_w);
+    (void)in_al; (void)out_al;
     switch (key) {
+#define UFD_LAUNCH(UP, DOWN, K, COLS, VW)                                                                                        \
+        {                                                                                                                         \
+            constexpr int TH_ = UfdTile<A, UP, DOWN, K, COLS, VW>::TH;                                                            \
+            const dim3 grid_((unsigned)((a.out_w + COLS * UFD_TW - 1) / (COLS * UFD_TW)), (unsigned)((a.out_h + TH_ - 1) / TH_), (unsigned)a.major); \
+            hipLaunchKernelGGL((k_upfirdn2d_tile<T, UP, DOWN, K, K, COLS, VW>), grid_, dim3(256), 0, s, a);                       \
+        }
 #define UFD_CASE(UP, DOWN, K) \
         case UP * 100 + DOWN * 10 + K: {                                                                                         \
-            if constexpr (sizeof(T) <= 4) {       /* half and float: pair accesses */                                             \
-                /* half: two output columns per lane (up-sampling and same-size filters; a down-sampling tile of 128 columns  */ \
-                /* needs a 36 KB patch and measured slower) or at least the column-pair staging                                */ \
-                if (vec_in && vec_out && DOWN == 1) {                                                                             \
-                    constexpr int TH2 = UfdTile<A, UP, DOWN, K, 2, true>::TH;                                                    \
-                    const dim3 grid2((unsigned)((a.out_w + 2 * UFD_TW - 1) / (2 * UFD_TW)), (unsigned)((a.out_h + TH2 - 1) / TH2), (unsigned)a.major); \
-                    hipLaunchKernelGGL((k_upfirdn2d_tile<T, UP, DOWN, K, K, 2, true>), grid2, dim3(256), 0, s, a);               \
-                    break;                                                                                                        \
-                }                                                                                                                 \
-                if (vec_in) {                                                                                                     \
-                    constexpr int TH1 = UfdTile<A, UP, DOWN, K, 1, true>::TH;                                                    \
-                    const dim3 grid1((unsigned)((a.out_w + UFD_TW - 1) / UFD_TW), (unsigned)((a.out_h + TH1 - 1) / TH1), (unsigned)a.major); \
-                    hipLaunchKernelGGL((k_upfirdn2d_tile<T, UP, DOWN, K, K, 1, true>), grid1, dim3(256), 0, s, a);               \
-                    break;                                                                                                        \
-                }                                                                                                                 \
+            /* half and float: several output columns per lane (up-sampling and same-size filters; a down-sampling tile that   */ \
+            /* wide needs a > 32 KB patch and measured slower) and / or the patch staged several input columns per load        */ \
+            if constexpr (sizeof(T) == 2) {                                                                                       \
+                if (in_al >= 4 && out_al >= 4 && DOWN == 1) { UFD_LAUNCH(UP, DOWN, K, 4, 4) break; }                               \
+                if (in_al >= 2 && out_al >= 2 && DOWN == 1) { UFD_LAUNCH(UP, DOWN, K, 2, 2) break; }                               \
+                if (in_al >= 4) { UFD_LAUNCH(UP, DOWN, K, 1, 4) break; }                                                           \
+                if (in_al >= 2) { UFD_LAUNCH(UP, DOWN, K, 1, 2) break; }                                                           \
             }                                                                                                                     \
-            constexpr int TH = UfdTile<A, UP, DOWN, K, 1, false>::TH;                                                                \
-            const dim3 grid((unsigned)((a.out_w + UFD_TW - 1) / UFD_TW), (unsigned)((a.out_h + TH - 1) / TH), (unsigned)a.major);   \
-            hipLaunchKernelGGL((k_upfirdn2d_tile<T, UP, DOWN, K, K, 1, false>), grid, dim3(256), 0, s, a);                           \
+            if constexpr (sizeof(T) == 4) {                                                                                       \
+                if (in_al >= 2 && out_al >= 2 && DOWN == 1) { UFD_LAUNCH(UP, DOWN, K, 2, 2) break; }                               \
+                if (in_al >= 2) { UFD_LAUNCH(UP, DOWN, K, 1, 2) break; }                                                           \
+            }                                                                                                                     \
+            UFD_LAUNCH(UP, DOWN, K, 1, 1)                                                                                         \
         } break;
         UFD_CASE(1, 1, 4) UFD_CASE(2, 1, 4) UFD_CASE(1, 2, 4)      // Blur, Upsample, Downsample (+ their backward passes)
         UFD_CASE(1, 2, 2) UFD_CASE(2, 1, 2)                        // Haar, inverse Haar
         UFD_CASE(1, 1, 2)
 #undef UFD_CASE
+#undef UFD_LAUNCH
         default: {
             size_t blocks = (total + 255) / 256;
             blocks = blocks > 16384 ? 16384 : blocks;

@@ -152,6 +152,26 @@ def test_stylegan_ops_native_dtypes(dtype, tol):
         assert float((out.view_as(r).double() - r).abs().max()) <= tol * max(1.0, float(r.abs().max())), name
 
 
+@pytest.mark.parametrize("dtype,tol", [(torch.float16, 2e-3), (torch.float32, 2e-6)], ids=["half", "float"])
+@pytest.mark.parametrize("width,offset", [(80, 0), (82, 0), (81, 0), (80, 2), (80, 1), (84, 3)])
+def test_upfirdn2d_vector_access_alignments(dtype, tol, width, offset):
+    """The tiled kernels stage the patch and store the outputs 1, 2 or 4 elements per access, chosen from the row pitch, the
+    plane size and the base alignment of each tensor: every combination (widths that are multiples of 4, of 2 only, odd;
+    bases offset by 1, 2, 3 elements) gives the same values."""
+    import upfirdn2d as U
+    from oracle import stylegan_oracle as SO
+    g = torch.Generator().manual_seed(width * 7 + offset)
+    n = 3 * 70 * width
+    flat = torch.randn(n + offset, generator=g).to(dtype).cuda()
+    x = flat[offset:].view(3, 70, width, 1)
+    assert x.data_ptr() % (4 * x.element_size()) == (offset * x.element_size()) % (4 * x.element_size())
+    for name, k, up, down, pad in STYLE_CASES:
+        out = U.upfirdn2d(x, k.to(dtype).cuda(), up, up, down, down, *pad)
+        r = SO.upfirdn2d(x.view(1, 3, 70, width).double(), k.to(dtype).double().cuda(), (up, up), (down, down), pad)
+        assert out.dtype == dtype
+        assert float((out.view_as(r).double() - r).abs().max()) <= tol * max(1.0, float(r.abs().max())), (name, width, offset)
+
+
 def test_stylegan_ops_reject_other_dtypes():
     import fused
     import upfirdn2d as U
