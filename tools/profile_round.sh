@@ -15,7 +15,7 @@ WORKLOAD="100000 1920 1080 0" PMC_VIEWS=1 PASSES="trace sq fetch write" bash too
 # graph-replayed s2 step: where one iteration's GPU time goes
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/gs -o g -- python $R/tools/profile_graph_step.py 64 > $R/gpurun_out/gs.log 2>&1
-python $R/tools/rocpd_summary.py $(find $R/gpurun_out/gs -name "*.db" | head -1) > $R/gpurun_out/prof_${N}_graph_step_kernels.md 2>&1
+python $R/tools/rocpd_summary.py $(find $R/gpurun_out/gs -name "*.db" | head -1) --cycles 60 --anchor k_adam_multi > $R/gpurun_out/prof_${N}_graph_step_kernels.md 2>&1
 grep "graphed s2 step" $R/gpurun_out/gs.log >> $R/gpurun_out/prof_${N}_graph_step_kernels.md
 rm -rf $R/gpurun_out/gs
 # the default bench line needs the traffic / VALU collections of THIS build in profiles/: copy them in on the box first
