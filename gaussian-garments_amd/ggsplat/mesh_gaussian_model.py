@@ -34,6 +34,17 @@ def _stream(dev):
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+def _f32c(t):
+    """float32 + contiguous; the common case (already both) costs two attribute reads instead of two dispatcher calls."""
+    if t is None or (t.dtype is torch.float32 and t.is_contiguous()):
+        return t
+    return t.contiguous().float()
+
+
+def _c(t):
+    return t if t is None or t.is_contiguous() else t.contiguous()
+
+
 class _MeshBind(torch.autograd.Function):
     """(verts, local_xyz, log_scaling, raw_rot) -> (xyz, scaling, rotation); faces / binding / bary constant."""
 
@@ -41,8 +52,7 @@ class _MeshBind(torch.autograd.Function):
     def forward(ctx, verts, local_xyz, log_scaling, raw_rot, faces, binding, bary):
         if verts.device.type != "cuda":
             raise RuntimeError("ggsplat mesh binding runs on the GPU only (no CPU path in the product)")
-        verts, local_xyz = verts.contiguous().float(), local_xyz.contiguous().float()
-        log_scaling, raw_rot = log_scaling.contiguous().float(), raw_rot.contiguous().float()
+        verts, local_xyz, log_scaling, raw_rot = _f32c(verts), _f32c(local_xyz), _f32c(log_scaling), _f32c(raw_rot)
         P, Fn = local_xyz.shape[0], faces.shape[0]
         xyz, scaling = torch.empty_like(local_xyz), torch.empty_like(log_scaling)
         rotation = torch.empty_like(raw_rot)
@@ -56,7 +66,7 @@ class _MeshBind(torch.autograd.Function):
     def backward(ctx, g_xyz, g_scaling, g_rot):
         verts, local_xyz, log_scaling, raw_rot, faces, binding, bary = ctx.saved_tensors
         P, Fn = local_xyz.shape[0], faces.shape[0]
-        c = (lambda t: None if t is None else t.contiguous().float())
+        c = _f32c
         d_verts = torch.zeros_like(verts)
         d_local, d_ls, d_rr = torch.empty_like(local_xyz), torch.empty_like(log_scaling), torch.empty_like(raw_rot)
         check(lib().ggs_mesh_bind_backward(P, Fn, ptr(verts), ptr(faces), ptr(binding), ptr(local_xyz),
@@ -68,8 +78,7 @@ class _MeshBind(torch.autograd.Function):
 
 def mesh_bind(verts, faces, binding, local_xyz, log_scaling, raw_rot, bary=None):
     """Fused forward (differentiable).  faces [F,3] int64, binding [P] int64, bary [P,3] or None."""
-    return _MeshBind.apply(verts, local_xyz, log_scaling, raw_rot, faces.contiguous(), binding.contiguous(),
-                           None if bary is None else bary.contiguous().float())
+    return _MeshBind.apply(verts, local_xyz, log_scaling, raw_rot, _c(faces), _c(binding), _f32c(bary))
 
 
 def visible_mask(verts, faces, binding, targets, camera, return_first_hit: bool = False):
