@@ -15,10 +15,9 @@ for p in (ROOT, PKG):
 # -- the NHWC implicit-GEMM assembly family (`igemm_bwd_gtcx35_nhwc_fp32_*`) -- faults on the small-channel shapes of these tests
 # depending on where the caching allocator happened to put the buffers (seen as "Memory access fault by GPU" in
 # test_graphed_appearance_step_with_a_convolutional_net when test_gpu_inner_step.py ran before it; AMD_LOG_LEVEL=3 shows the
-# igemm trial as the last kernel).  Not a kernel of this repo: the family is taken out of the trial list.
-for _k in ("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_FWD_GTC_XDLOPS_NHWC", "MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC",
-           "MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_WRW_GTC_XDLOPS_NHWC"):
-    os.environ.setdefault(_k, "0")
+# igemm trial as the last kernel).  Not a kernel of this repo: the backward-data solvers of the family are taken out of the
+# trial list.
+os.environ.setdefault("MIOPEN_DEBUG_CONV_IMPLICIT_GEMM_ASM_BWD_GTC_XDLOPS_NHWC", "0")
 
 
 def pytest_configure(config):
