@@ -10,7 +10,7 @@
 //          keys[cap] (u64: depth bits << 32 | Gaussian id << 4 | quadrant mask) | ids[cap] (u32:
 //          quadrant mask << 28 | id, sorted by (depth bits, id))
 //          (BinHeader bytes 64.. hold the 8 list-length bucket counters / cursors of `order`)
-//   img  : final_T[V][H*W] f32 | n_contrib[V][H*W] u32
+//   img  : final_T[V][H*W] f32 | n_contrib[V][H*W] u32   (defined on the pixels of NON-EMPTY tiles only: nothing reads the rest)
 //   bwd scratch : GradRec acc[V][P]      48 B per (view, Gaussian), atomically accumulated
 //                                        per-Gaussian screen-space gradients.
 #pragma once

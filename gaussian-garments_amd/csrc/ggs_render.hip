@@ -26,10 +26,13 @@
 namespace {
 
 // Empty tile (~90 % of the tiles of a view) fully inside the image: nothing to composite, the wave only stores the
-// background.  Lane l owns 4 consecutive pixels of row l / 4, so each of the 7 planes leaves as ONE 16-byte store per lane
+// background.  Lane l owns 4 consecutive pixels of row l / 4, so each plane leaves as ONE 16-byte store per lane
 // (16 rows x 64 contiguous bytes) instead of four 4-byte stores in the quadrant layout.  Where most of a launch is background
-// (config 5: 4K frames) the forward is bound by exactly these stores.  Returns false when the tile must take the general path
-// (image edge, row pitch not a multiple of 16 bytes).
+// (config 5: 4K frames) the forward is bound by exactly these stores -- and 9 of 10 bytes the forward writes at config 2 come
+// from here -- so only the five OUTPUT planes are written: the per-pixel workspace (final_T, n_contrib) of an empty tile is
+// never read (the backward and ggs_count_blends return on tile_count == 0 before touching it) and stays undefined
+// (forward 27-29 -> 25 us per view at config 2, 109 -> 100 at config 5).  Returns false when the tile must take the
+// general path (image edge, row pitch not a multiple of 16 bytes).
 __device__ __forceinline__ bool store_empty_tile(const RenderArgs& a, int v, int ox, int oy, int lane) {
     if ((a.W & 3) != 0 || ox + GGS_TILE > a.W || oy + GGS_TILE > a.H) return false;
     const size_t HW = (size_t)a.H * a.W;
@@ -42,8 +45,6 @@ __device__ __forceinline__ bool store_empty_tile(const RenderArgs& a, int v, int
     *reinterpret_cast<float4*>(oc + 2 * HW) = make_float4(b2, b2, b2, b2);
     *reinterpret_cast<float4*>(a.out_depth + (size_t)v * HW + pix) = make_float4(0.f, 0.f, 0.f, 0.f);
     *reinterpret_cast<float4*>(a.out_alpha + (size_t)v * HW + pix) = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(a.final_T + (size_t)v * HW + pix) = make_float4(1.f, 1.f, 1.f, 1.f);
-    *reinterpret_cast<uint4*>(a.n_contrib + (size_t)v * HW + pix) = make_uint4(0, 0, 0, 0);
     return true;
 }
 
@@ -55,8 +56,8 @@ __device__ __forceinline__ bool store_empty_tile(const RenderArgs& a, int v, int
 __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
     constexpr int NQ = 4, q0 = 0;
     // A forward that overflowed its binning capacity (only possible with a static capacity inside a captured graph) has no
-    // lists: every tile is composited as EMPTY, so the outputs are deterministic (background, zero depth / alpha,
-    // final_T = 1, n_contrib = 0) instead of uninitialised memory.  The overflow word tells the caller to re-run.
+    // lists: every tile is composited as EMPTY, so the outputs are deterministic (background, zero depth / alpha)
+    // instead of uninitialised memory.  The overflow word tells the caller to re-run.
     const bool overflow = a.header->overflow != 0;
     const uint32_t item = a.order[blockIdx.x];   // work items, longest lists first
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;

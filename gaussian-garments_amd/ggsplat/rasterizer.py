@@ -282,13 +282,20 @@ def bin_sections(st: ForwardState) -> Dict[str, torch.Tensor]:
 
 
 def img_sections(st: ForwardState) -> Dict[str, torch.Tensor]:
-    """Typed views into the image workspace of a forward: final_T [V,H,W] f32 and n_contrib [V,H,W] i32 (1-based list
-    position of the last contributor)."""
+    """The image workspace of a forward (tests / debugging): final_T [V,H,W] f32 and n_contrib [V,H,W] i32 (1-based list
+    position of the last contributor).  The kernels leave the workspace of EMPTY tiles undefined -- nothing on the device reads
+    it -- so the copies returned here carry the values an empty tile has by definition there (final_T = 1, n_contrib = 0)."""
     V, H, W = st.prm.n_views, st.prm.H, st.prm.W
     n = V * H * W * 4
     off = (n + 255) & ~255
-    return dict(final_T=st.img[:n].view(torch.float32).reshape(V, H, W),
-                n_contrib=st.img[off:off + n].view(torch.int32).reshape(V, H, W))
+    final_T = st.img[:n].view(torch.float32).reshape(V, H, W).clone()
+    n_contrib = st.img[off:off + n].view(torch.int32).reshape(V, H, W).clone()
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    empty = (bin_sections(st)["tile_count"].reshape(V, gy, gx) == 0)
+    empty = empty.repeat_interleave(16, 1).repeat_interleave(16, 2)[:, :H, :W]
+    final_T[empty] = 1.0
+    n_contrib[empty] = 0
+    return dict(final_T=final_T, n_contrib=n_contrib)
 
 
 class _RasterizeGaussians(torch.autograd.Function):

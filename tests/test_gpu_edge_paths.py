@@ -143,3 +143,50 @@ def test_work_order_is_a_permutation_for_odd_shapes(P, W, H, V, scale):
     # and the launch composited every pixel: alpha + final_T == 1 up to rounding wherever something was blended
     fT = R.img_sections(st)["final_T"]
     assert float((alpha + fT - 1.0).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("n_views", [1, 8], ids=["quad_waves", "tile_waves"])
+def test_backward_never_reads_the_workspace_of_empty_tiles(n_views):
+    """The forward stores the per-pixel workspace (final_T, n_contrib) only where a tile has a list -- ~90 % of the tiles of a
+    view are empty and their two planes were a quarter of everything the forward wrote.  Contract: nothing on the device reads
+    the workspace of an empty tile.  Here it is POISONED (NaN / huge positions) between forward and backward, in both
+    mappings: the gradients must come out as without the poison, and ggs_count_blends must count the same pairs."""
+    import ctypes as C
+    from ggsplat import _lib, rasterizer as R
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    dev = "cuda"
+    W, H = 640, 360
+    v, f = S.skirt_mesh(40, 60)
+    m = MeshGaussianModel.from_tensors(v, f, S.skirt_gaussian_params(f.shape[0], 0), 0, device=dev)
+    cams = S.rig_cameras(n_rings=1, n_az=8, width=W, height=H, f=500.0)[:n_views]
+    ck = S.stack_cameras(cams, device=dev)
+    dL = torch.randn(n_views, 3, H, W, generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def run(poison):
+        with torch.no_grad():
+            m.update_face_coor()
+            color, radii, depth, alpha, st = R.forward_views(
+                m.get_xyz, m.get_opacity, m.get_features, None, m.get_scaling, m.get_rotation, None, view=ck["view"],
+                proj=ck["proj"], campos=ck["campos"], tanfov=ck["tanfov"], bg=torch.zeros(3, device=dev), W=W, H=H, sh_degree=0)
+            gx, gy = (W + 15) // 16, (H + 15) // 16
+            empty = (R.bin_sections(st)["tile_count"].reshape(n_views, gy, gx) == 0)
+            empty_px = empty.repeat_interleave(16, 1).repeat_interleave(16, 2)[:, :H, :W]
+            frac_empty = float(empty.float().mean())
+            if poison:
+                n = n_views * H * W * 4
+                off = (n + 255) & ~255
+                st.img[:n].view(torch.float32).reshape(n_views, H, W)[empty_px] = float("nan")
+                st.img[off:off + n].view(torch.int32).reshape(n_views, H, W)[empty_px] = 0x7fffffff
+            count = torch.zeros(1, dtype=torch.int64, device=dev)
+            _lib.check(_lib.lib().ggs_count_blends(C.byref(st.prm), st.geom.data_ptr(), st.bin.data_ptr(), st.cap, st.img.data_ptr(),
+                                                   count.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                       "ggs_count_blends")
+            g = R.backward_views(st, dL, want_means2D=True)
+        return {k: t.clone() for k, t in g.items() if torch.is_tensor(t)}, int(count.item()), frac_empty
+
+    clean, n_clean, frac_empty = run(False)
+    dirty, n_dirty, _ = run(True)
+    assert frac_empty > 0.3 and n_clean > 0 and n_dirty == n_clean
+    for k in clean:
+        assert torch.isfinite(dirty[k]).all(), k
+        assert rel_l1(dirty[k], clean[k]) <= 1e-6, k

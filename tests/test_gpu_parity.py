@@ -133,9 +133,7 @@ def test_internals_bit_exact():
     co = COracle(means3D=sc["means3D"], opacities=sc["opacities"], shs=sc["shs"], scales=sc["scales"],
                  rotations=sc["rotations"], sh_degree=0, **cam_kwargs(cam, (0, 0, 0)))
     it = co.internals()
-    HW = 160 * 120
-    img = st.img.cpu()
-    final_T = img[:HW * 4].view(torch.float32).reshape(120, 160)
+    final_T = R.img_sections(st)["final_T"][0].cpu()       # (empty tiles: 1 by definition, the kernels do not store them)
     assert rel_l1(final_T, it["final_T"]) <= REL_L1_TOL
     assert rel_l1(color[0], co.color) <= REL_L1_TOL and rel_l1(alpha, co.alpha) <= REL_L1_TOL
     # Binning: the HIP lists may DROP (splat, tile) pairs whose alpha can never reach 1/255 inside the tile
@@ -177,7 +175,7 @@ def test_internals_bit_exact():
     last_hip = ids[(offs[tile] + n_hip - 1)[has]].astype(np.int64)
     last_ref = it["list"][(it["tile_start"][tile] + n_ref - 1)[has]].astype(np.int64)
     assert np.array_equal(last_hip, last_ref), f"{int((last_hip != last_ref).sum())} of {int(has.sum())} pixels end on another Gaussian"
-    assert has.sum() > 0.3 * HW
+    assert has.sum() > 0.3 * 160 * 120
     # per-Gaussian records: bit-exact geometry (floats 0..9 of the 48-byte record)
     rec = st.geom.cpu()[:3000 * 48].view(torch.float32).reshape(3000, 12).numpy()
     vis = co.radii > 0
