@@ -40,7 +40,28 @@ struct LossArgs {
     float* sums;                      // [V][2] = {sum |x - y|, sum ssim_map}
     float* dmap;                      // [V][3 channels][3 maps][H][W] scratch
     float* dL_dimg;                   // [V][3][H][W]
+    const uint32_t* tile_count;       // region-of-interest form: [V][tgy * tgx] list lengths of the forward's 16x16 tiles, or null
+    int tgx, tgy;
 };
+
+// Region of interest.  dL/dimage reaches a parameter only through pixels of tiles that HAVE a list (the render backward returns
+// on an empty tile before it reads anything): with the forward's tile_count at hand, pass B runs only the boxes (64-column
+// strip x LS_HB_ROI-row band) that overlap a non-empty tile and leaves dL/dimage alone elsewhere.  What is left of pass B is a
+// few hundred waves, each bound by its chain of row steps -- so the region-of-interest pass uses SHORT bands (12 rows: 22 row
+// steps per wave instead of 44; the 1.8 x filtered rows that made short bands lose on a whole image no longer matter).
+// A box of pass B reads the derivative maps up to LH pixels outside itself: within the strips next to its own, and within
+// LH + LS_HB_ROI - 1 rows of the non-empty tile that made it active -- pass A stores the maps of a box iff a non-empty tile
+// lies within that distance of it, and skips the derivative arithmetic otherwise; its sums cover every pixel as before.
+// any_tile: does a non-empty tile of view v intersect the pixel rectangle [x0, x1] x [y0, y1]?  (wave-uniform result)
+__device__ __forceinline__ bool any_tile(const LossArgs& a, int v, int x0, int y0, int x1, int y1, int lane) {
+    const int tx0 = max(x0, 0) >> 4, tx1 = min(min(x1, a.W - 1) >> 4, a.tgx - 1);
+    const int ty0 = max(y0, 0) >> 4, ty1 = min(min(y1, a.H - 1) >> 4, a.tgy - 1);
+    const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
+    const uint32_t* tc = a.tile_count + (size_t)v * a.tgx * a.tgy;
+    bool hit = false;
+    for (int i = lane; i < n; i += 64) hit |= tc[(size_t)(ty0 + i / nx) * a.tgx + tx0 + i % nx] != 0;
+    return __builtin_amdgcn_ballot_w64(hit) != 0;
+}
 
 __device__ __forceinline__ float block_sum(float v, float* s_red) {
 #pragma unroll
@@ -72,6 +93,7 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
                                           // 2.8x the waves, half the dependent row steps each, 1.8x the filtered rows --
                                           // measured 0.166 against 0.104 ms per 1080p view: the pass is bound by its VALU
                                           // work per row, not by the latency of a row step.)
+#define LS_HB_ROI 12                      // band height of pass B in the region-of-interest form (see any_tile)
 #define LS_IN (LS_COLS + 2 * LH)          // 74
 #define LS_WAVES 4                        // waves per workgroup: consecutive bands of one strip
 
@@ -119,7 +141,7 @@ __device__ __forceinline__ StatsRow stats_load_row(const float* __restrict__ img
 
 struct StatsCtx {
     const float *img, *gt, *mask;
-    float* dm;
+    float* dm;                // null: the maps of this box are not needed (region-of-interest form)
     int H, W, oy, ox, lane;
     size_t HW;
     float (*sx)[LS_IN];       // [2][LS_IN] wave-private
@@ -142,7 +164,7 @@ __device__ __forceinline__ void stats_step(StatsCtx& c, RowRing<5>& ring, int i)
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (c.pend) {                                                        // output row i - 1 - 2 LH
+    if (c.pend && c.dm) {                                                // output row i - 1 - 2 LH
         const size_t p = (size_t)(c.oy + i - 1 - 2 * LH) * c.W + x;
         c.dm[p] = c.o0; c.dm[c.HW + p] = c.o1; c.dm[2 * c.HW + p] = c.o2;
     }
@@ -175,9 +197,11 @@ __device__ __forceinline__ void stats_step(StatsCtx& c, RowRing<5>& ring, int i)
         const float inv = iB1 * iB2;
         const float S = A1 * A2 * inv;
         if (c.pend) c.ssum += S;
-        c.o0 = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * iB1 + 2.f * m1 * S * iB2;
-        c.o1 = -S * iB2;
-        c.o2 = 2.f * A1 * inv;
+        if (c.dm) {                                  // wave-uniform: null where nobody will read the maps of this box
+            c.o0 = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * iB1 + 2.f * m1 * S * iB2;
+            c.o1 = -S * iB2;
+            c.o2 = 2.f * A1 * inv;
+        }
     }
 }
 
@@ -208,6 +232,9 @@ __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float 
     c.H = a.H; c.W = a.W; c.oy = band * LS_HB; c.ox = blockIdx.x * LS_COLS; c.lane = lane; c.HW = HW;
     c.sx = s_x[wave]; c.sy = s_y[wave];
     c.l1 = 0.f; c.ssum = 0.f; c.pend = false; c.o0 = c.o1 = c.o2 = 0.f;
+    if (a.tile_count && c.oy < a.H &&
+        !any_tile(a, v, c.ox - LS_COLS, c.oy - (LH + LS_HB_ROI - 1), c.ox + 2 * LS_COLS - 1, c.oy + LS_HB - 1 + LH + LS_HB_ROI - 1, lane))
+        c.dm = nullptr;
     if (c.oy < a.H) {
         RowRing<5> ring;
 #pragma unroll
@@ -216,7 +243,7 @@ __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float 
             for (int m = 0; m < 5; ++m) ring.v[j][m] = 0.f;
         c.nxt = stats_load_row<MASK>(c.img, c.gt, c.mask, c.oy - LH, c.H, c.W, c.ox, lane);
         for (int i0 = 0; i0 < LS_HB + 2 * LH; i0 += 11) unroll11<0, StatsStep<MASK>>(c, ring, i0);
-        if (c.pend) {                                                    // the last output row
+        if (c.pend && c.dm) {                                            // the last output row
             const size_t p = (size_t)(c.oy + LS_HB - 1) * c.W + c.ox + lane;
             c.dm[p] = c.o0; c.dm[HW + p] = c.o1; c.dm[2 * HW + p] = c.o2;
         }
@@ -318,7 +345,7 @@ struct GradStep {
     template <int R> static __device__ __forceinline__ void run(GradCtx& c, RowRing<3>& r, int i) { grad_step<R, MASK>(c, r, i); }
 };
 
-template <bool MASK>
+template <bool MASK, int HB>
 __device__ __forceinline__ void loss_grad_stream_body(const LossArgs& a, float (*s_d)[2][3][LS_IN]) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int v = blockIdx.z / 3, ch = blockIdx.z % 3;
@@ -330,19 +357,21 @@ __device__ __forceinline__ void loss_grad_stream_body(const LossArgs& a, float (
     c.mask = !MASK ? nullptr : a.mask_tab ? a.mask_tab[v] : a.mask + (size_t)v * HW;
     c.dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW;
     c.out = a.dL_dimg + ((size_t)v * 3 + ch) * HW;
-    c.H = a.H; c.W = a.W; c.oy = band * LS_HB; c.ox = blockIdx.x * LS_COLS; c.lane = lane; c.HW = HW;
+    c.H = a.H; c.W = a.W; c.oy = band * HB; c.ox = blockIdx.x * LS_COLS; c.lane = lane; c.HW = HW;
     c.w_l1 = a.w[2 * v] * a.inv_n; c.w_ssim = a.w[2 * v + 1] * a.inv_n;
     c.sd = s_d[wave];
     c.pend = false; c.o0 = 0.f;
     if (c.oy >= a.H) return;
+    if (a.tile_count && !any_tile(a, v, c.ox, c.oy, c.ox + LS_COLS - 1, c.oy + HB - 1, lane)) return;
     RowRing<3> ring;
 #pragma unroll
     for (int j = 0; j < 11; ++j)
 #pragma unroll
         for (int m = 0; m < 3; ++m) ring.v[j][m] = 0.f;
     c.nxt = grad_load_row<MASK>(c.dm, c.img, c.gt, c.mask, HW, c.oy - LH, c.oy - 2 * LH, c.H, c.W, c.ox, lane);
-    for (int i0 = 0; i0 < LS_HB + 2 * LH; i0 += 11) unroll11<0, GradStep<MASK>>(c, ring, i0);
-    if (c.pend) c.out[(size_t)(c.oy + LS_HB - 1) * c.W + c.ox + lane] = c.o0;
+    static_assert((HB + 2 * LH) % 11 == 0, "the row loop is unrolled by 11");
+    for (int i0 = 0; i0 < HB + 2 * LH; i0 += 11) unroll11<0, GradStep<MASK>>(c, ring, i0);
+    if (c.pend) c.out[(size_t)(c.oy + HB - 1) * c.W + c.ox + lane] = c.o0;
 }
 
 }  // namespace
@@ -350,8 +379,14 @@ __device__ __forceinline__ void loss_grad_stream_body(const LossArgs& a, float (
 // Pass B: same decomposition as pass A.
 __global__ __launch_bounds__(256) void ggs_k_loss_grad(LossArgs a) {
     __shared__ float s_d[LS_WAVES][2][3][LS_IN];
-    if (a.mask || a.mask_tab) loss_grad_stream_body<true>(a, s_d);
-    else loss_grad_stream_body<false>(a, s_d);
+    if (a.mask || a.mask_tab) loss_grad_stream_body<true, LS_HB>(a, s_d);
+    else loss_grad_stream_body<false, LS_HB>(a, s_d);
+}
+// Pass B of the region-of-interest form: bands of LS_HB_ROI rows, only the boxes that overlap a non-empty tile do anything.
+__global__ __launch_bounds__(256) void ggs_k_loss_grad_roi(LossArgs a) {
+    __shared__ float s_d[LS_WAVES][2][3][LS_IN];
+    if (a.mask || a.mask_tab) loss_grad_stream_body<true, LS_HB_ROI>(a, s_d);
+    else loss_grad_stream_body<false, LS_HB_ROI>(a, s_d);
 }
 
 extern "C" {
@@ -362,7 +397,8 @@ size_t ggs_photometric_scratch_bytes(int n_views, int H, int W) {
 }
 
 static int loss_args(LossArgs& a, int n_views, int H, int W, const float* img, const float* gt, const float* mask,
-                     const float* const* gt_tab, const float* const* mask_tab, void* scratch, const char* who) {
+                     const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count, void* scratch,
+                     const char* who) {
     ggs_clear_error_();
     if (n_views <= 0 || H <= 0 || W <= 0) return ggs_fail_(GGS_ERR_ARG, "%s: bad sizes", who);
     if (!img || !(gt || gt_tab) || !scratch) return ggs_fail_(GGS_ERR_ARG, "%s: NULL pointer argument", who);
@@ -370,14 +406,15 @@ static int loss_args(LossArgs& a, int n_views, int H, int W, const float* img, c
     a.V = n_views; a.H = H; a.W = W; a.img = img; a.gt = gt; a.mask = mask; a.gt_tab = gt_tab; a.mask_tab = mask_tab;
     a.inv_n = 1.f / (3.f * (float)H * (float)W);
     a.w = nullptr; a.sums = nullptr; a.dL_dimg = nullptr; a.dmap = (float*)scratch;
+    a.tile_count = tile_count; a.tgx = (W + 15) / 16; a.tgy = (H + 15) / 16;
     return GGS_OK;
 }
 
 static int photometric_forward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
-                               const float* const* gt_tab, const float* const* mask_tab, float* sums, void* scratch,
-                               void* stream_) {
+                               const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count,
+                               float* sums, void* scratch, void* stream_) {
     LossArgs a;
-    int rc = loss_args(a, n_views, H, W, img, gt, mask, gt_tab, mask_tab, scratch, "ggs_photometric_forward");
+    int rc = loss_args(a, n_views, H, W, img, gt, mask, gt_tab, mask_tab, tile_count, scratch, "ggs_photometric_forward");
     if (rc != GGS_OK) return rc;
     if (!sums) return ggs_fail_(GGS_ERR_ARG, "ggs_photometric_forward: sums is NULL");
     hipStream_t s = (hipStream_t)stream_;
@@ -394,16 +431,18 @@ static int photometric_forward(int n_views, int H, int W, const float* img, cons
 }
 
 static int photometric_backward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
-                                const float* const* gt_tab, const float* const* mask_tab, const void* scratch,
-                                const float* weights, float* dL_dimg, void* stream_) {
+                                const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count,
+                                const void* scratch, const float* weights, float* dL_dimg, void* stream_) {
     LossArgs a;
-    int rc = loss_args(a, n_views, H, W, img, gt, mask, gt_tab, mask_tab, (void*)scratch, "ggs_photometric_backward");
+    int rc = loss_args(a, n_views, H, W, img, gt, mask, gt_tab, mask_tab, tile_count, (void*)scratch, "ggs_photometric_backward");
     if (rc != GGS_OK) return rc;
     if (!weights || !dL_dimg) return ggs_fail_(GGS_ERR_ARG, "ggs_photometric_backward: NULL pointer argument");
     a.w = weights; a.dL_dimg = dL_dimg;
-    const int bands = (H + LS_HB - 1) / LS_HB;
+    const int hb = tile_count ? LS_HB_ROI : LS_HB;
+    const int bands = (H + hb - 1) / hb;
     const dim3 grid((unsigned)((W + LS_COLS - 1) / LS_COLS), (unsigned)((bands + LS_WAVES - 1) / LS_WAVES), (unsigned)(n_views * 3));
-    hipLaunchKernelGGL(ggs_k_loss_grad, grid, dim3(256), 0, (hipStream_t)stream_, a);
+    if (tile_count) hipLaunchKernelGGL(ggs_k_loss_grad_roi, grid, dim3(256), 0, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL(ggs_k_loss_grad, grid, dim3(256), 0, (hipStream_t)stream_, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "loss_grad launch failed: %s", hipGetErrorString(e));
     return GGS_OK;
@@ -411,23 +450,37 @@ static int photometric_backward(int n_views, int H, int W, const float* img, con
 
 int ggs_photometric_forward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
                             float* sums, void* scratch, void* stream) {
-    return photometric_forward(n_views, H, W, img, gt, mask, nullptr, nullptr, sums, scratch, stream);
+    return photometric_forward(n_views, H, W, img, gt, mask, nullptr, nullptr, nullptr, sums, scratch, stream);
 }
 int ggs_photometric_backward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
                              const void* scratch, const float* weights, float* dL_dimg, void* stream) {
-    return photometric_backward(n_views, H, W, img, gt, mask, nullptr, nullptr, scratch, weights, dL_dimg, stream);
+    return photometric_backward(n_views, H, W, img, gt, mask, nullptr, nullptr, nullptr, scratch, weights, dL_dimg, stream);
 }
 // Table form: the ground-truth images (and masks) are named by DEVICE-resident pointer tables that the kernels read at run
 // time, so a captured hipGraph can be replayed on another camera's images by rewriting 8 bytes per image instead of copying
 // 33 MB into static buffers.
 int ggs_photometric_forward_tab(int n_views, int H, int W, const float* img, const float* const* gt_tab,
                                 const float* const* mask_tab, float* sums, void* scratch, void* stream) {
-    return photometric_forward(n_views, H, W, img, nullptr, nullptr, gt_tab, mask_tab, sums, scratch, stream);
+    return photometric_forward(n_views, H, W, img, nullptr, nullptr, gt_tab, mask_tab, nullptr, sums, scratch, stream);
 }
 int ggs_photometric_backward_tab(int n_views, int H, int W, const float* img, const float* const* gt_tab,
                                  const float* const* mask_tab, const void* scratch, const float* weights, float* dL_dimg,
                                  void* stream) {
-    return photometric_backward(n_views, H, W, img, nullptr, nullptr, gt_tab, mask_tab, scratch, weights, dL_dimg, stream);
+    return photometric_backward(n_views, H, W, img, nullptr, nullptr, gt_tab, mask_tab, nullptr, scratch, weights, dL_dimg, stream);
+}
+// Region-of-interest form (see any_tile above): `tile_count` = the list lengths of the forward that rendered `img`
+// (section 1 of ggs_bin_layout: uint32 [n_views][ceil(H/16) * ceil(W/16)]).  The sums are those of the plain form; dL/dimg is
+// written only in the boxes that overlap a non-empty tile and left untouched elsewhere.  Images by plain pointers (gt / mask)
+// or by tables (gt_tab / mask_tab), as in the two forms above.
+int ggs_photometric_forward_roi(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
+                                const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count,
+                                float* sums, void* scratch, void* stream) {
+    return photometric_forward(n_views, H, W, img, gt, mask, gt_tab, mask_tab, tile_count, sums, scratch, stream);
+}
+int ggs_photometric_backward_roi(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
+                                 const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count,
+                                 const void* scratch, const float* weights, float* dL_dimg, void* stream) {
+    return photometric_backward(n_views, H, W, img, gt, mask, gt_tab, mask_tab, tile_count, scratch, weights, dL_dimg, stream);
 }
 
 }  // extern "C"

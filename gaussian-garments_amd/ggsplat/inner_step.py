@@ -26,10 +26,14 @@ DEFAULT_PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=Fa
 
 def _photometric(image, gt_image, m, lam, fused: bool):
     """The two image terms of both loops: L1 * (1 - lambda) and 1 - SSIM * lambda.  fused=True: one pair of HIP
-    kernels (ggs_photometric_*); fused=False: the reference's PyTorch composition (loss.py), which also masks
-    `image` and `gt_image` in place like the reference does."""
+    kernels (ggs_photometric_*) in their region-of-interest form -- the image is the output of the render() call just
+    made on this thread, and its gradient is only needed on the pixels of tiles that have a splat list; fused=False: the
+    reference's PyTorch composition (loss.py), which also masks `image` and `gt_image` in place like the reference does."""
     if fused:
-        return fused_photometric_loss(image, gt_image, m, lam)
+        tc = R.last_tile_count()
+        if tc is not None and tc.shape != (1, ((image.shape[-2] + 15) // 16) * ((image.shape[-1] + 15) // 16)):
+            tc = None                                   # not the forward of this image
+        return fused_photometric_loss(image, gt_image, m, lam, tile_count=tc)
     return l1_loss(image, gt_image, m) * (1.0 - lam), 1.0 - ssim(image, gt_image, m) * lam
 
 
@@ -240,11 +244,13 @@ class GraphedRegistrationStep:
             use_m = self.mask is not None and opt.only_foreground_loss
             gt_tab, m_tab = self._ptrs[0:1], (self._ptrs[1:2] if use_m else None)
             scratch = torch.empty(L.ggs_photometric_scratch_bytes(1, H, W), device=dev, dtype=torch.uint8)
-            check(L.ggs_photometric_forward_tab(1, H, W, ptr(color), ptr(gt_tab), ptr(m_tab), ptr(self._stats[0:2]),
-                                                ptr(scratch), stream), "ggs_photometric_forward_tab")
+            # region-of-interest form: dL/dimage only where the backward below reads it (tiles with a list: ~1 in 10 here)
+            tc = R.last_tile_count()
+            check(L.ggs_photometric_forward_roi(1, H, W, ptr(color), None, None, ptr(gt_tab), ptr(m_tab), ptr(tc),
+                                                ptr(self._stats[0:2]), ptr(scratch), stream), "ggs_photometric_forward_roi")
             dimg = torch.empty_like(color)
-            check(L.ggs_photometric_backward_tab(1, H, W, ptr(color), ptr(gt_tab), ptr(m_tab), ptr(scratch), ptr(self._w),
-                                                 ptr(dimg), stream), "ggs_photometric_backward_tab")
+            check(L.ggs_photometric_backward_roi(1, H, W, ptr(color), None, None, ptr(gt_tab), ptr(m_tab), ptr(tc), ptr(scratch),
+                                                 ptr(self._w), ptr(dimg), stream), "ggs_photometric_backward_roi")
             gr = R.backward_views(st, dimg, want_means2D=True)
             d_verts = torch.zeros_like(verts)
             d_xyz, d_ls, d_rr = torch.empty_like(g._xyz), torch.empty_like(g._scaling), torch.empty_like(g._rotation)

@@ -45,7 +45,7 @@ def ssim(img1, img2, mask=None, window_size=11, size_average=True):
 # steps and the gradient w.r.t. the rendered image in two tile passes instead of ~25 PyTorch kernels.
 class _FusedPhotometric(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, gt, mask, lambda_dssim):
+    def forward(ctx, image, gt, mask, lambda_dssim, tile_count=None):
         import ctypes as C
         from ._lib import check, lib, ptr
         if image.device.type != "cuda":
@@ -63,37 +63,47 @@ class _FusedPhotometric(torch.autograd.Function):
         dev = img.device
         sums = torch.empty(V, 2, device=dev, dtype=torch.float32)
         scratch = torch.empty(L.ggs_photometric_scratch_bytes(V, H, W), device=dev, dtype=torch.uint8)
-        check(L.ggs_photometric_forward(V, H, W, ptr(img), ptr(g), ptr(m), ptr(sums), ptr(scratch),
-                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+        tc = None
+        if tile_count is not None:
+            tc = tile_count.contiguous()
+            if tc.dtype not in (torch.int32, torch.uint32) or tc.numel() != V * ((H + 15) // 16) * ((W + 15) // 16):
+                raise ValueError("fused_photometric_loss: tile_count must be int32 [V, ceil(H/16) * ceil(W/16)]")
+        check(L.ggs_photometric_forward_roi(V, H, W, ptr(img), ptr(g), ptr(m), None, None, ptr(tc), ptr(sums), ptr(scratch),
+                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
               "ggs_photometric_forward")
         lam = float(lambda_dssim)
         n = 3.0 * H * W
-        ctx.saved = (img.clone() if img.data_ptr() == image.data_ptr() else img, g, m, scratch, lam, image.shape)
+        ctx.saved = (img.clone() if img.data_ptr() == image.data_ptr() else img, g, m, scratch, lam, image.shape, tc)
         return sums[:, 0] / n * (1.0 - lam), 1.0 - sums[:, 1] / n * lam
 
     @staticmethod
     def backward(ctx, g_img, g_ssim):
         import ctypes as C
         from ._lib import check, lib, ptr
-        img, g, m, scratch, lam, in_shape = ctx.saved
+        img, g, m, scratch, lam, in_shape, tc = ctx.saved
         V, _, H, W = img.shape
         dev = img.device
         z = torch.zeros(V, device=dev)
         w = torch.stack([(g_img if g_img is not None else z).reshape(V) * (1.0 - lam),
                          (g_ssim if g_ssim is not None else z).reshape(V) * (-lam)], dim=1).float().contiguous()
-        dimg = torch.empty_like(img)
-        check(lib().ggs_photometric_backward(V, H, W, ptr(img), ptr(g), ptr(m), ptr(scratch), ptr(w), ptr(dimg),
-                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+        # region of interest: the kernels leave dL/dimage alone outside the boxes that touch a non-empty tile -- zero there, so
+        # that a gradient summed with other consumers of the image stays finite
+        dimg = torch.empty_like(img) if tc is None else torch.zeros_like(img)
+        check(lib().ggs_photometric_backward_roi(V, H, W, ptr(img), ptr(g), ptr(m), None, None, ptr(tc), ptr(scratch), ptr(w),
+                                                 ptr(dimg), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
               "ggs_photometric_backward")
-        return dimg.reshape(in_shape), None, None, None
+        return dimg.reshape(in_shape), None, None, None, None
 
 
-def fused_photometric_loss(image, gt, mask=None, lambda_dssim: float = 0.2):
+def fused_photometric_loss(image, gt, mask=None, lambda_dssim: float = 0.2, tile_count=None):
     """(l1_loss(image, gt, mask) * (1 - lambda), 1 - ssim(image, gt, mask) * lambda), per view when the inputs
     are batched [V,3,H,W], through the fused HIP kernels.  Unlike the reference's ssim() it does not mask
     `image` / `gt` in place (the masking happens inside the kernels); the image is copied for the backward
-    because callers may still mutate the rasterizer's output."""
-    l_img, l_ssim = _FusedPhotometric.apply(image, gt, mask, lambda_dssim)
+    because callers may still mutate the rasterizer's output.
+    tile_count (rasterizer.last_tile_count() of the forward that rendered `image`): region-of-interest form -- the loss
+    VALUES are the same, the gradient w.r.t. the image is computed only where the rasterizer's backward reads it (pixels of
+    tiles that have a list) and is zero elsewhere: right for every parameter behind the rasterizer, not a full dL/dimage."""
+    l_img, l_ssim = _FusedPhotometric.apply(image, gt, mask, lambda_dssim, tile_count)
     if image.dim() == 3:
         return l_img[0], l_ssim[0]
     return l_img, l_ssim

@@ -35,6 +35,17 @@ def last_header() -> Optional[torch.Tensor]:
     return getattr(_pinned, "last_header", None)
 
 
+def last_tile_count() -> Optional[torch.Tensor]:
+    """List lengths of the 16x16 tiles of this thread's most recent forward: int32 [V, ceil(H/16) * ceil(W/16)], a view into
+    that forward's binning buffer (which it keeps alive).  The region-of-interest form of the fused loss takes it
+    (loss.fused_photometric_loss(..., tile_count=...)): dL/dimage is only needed where a tile has a list."""
+    b = getattr(_pinned, "last_bin", None)
+    if b is None:
+        return None
+    binb, V, T, off = b
+    return binb[off:off + V * T * 4].view(torch.int32).reshape(V, T)
+
+
 # headers of the forwards issued while a stream was being captured (the graph owner checks their overflow words)
 _capture_headers: list = []
 
@@ -61,6 +72,18 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 _ws_sizes: Dict[Tuple, Tuple[int, int, int]] = {}
+_tc_off: Dict[Tuple, int] = {}
+
+
+def _tile_count_offset(L, prm, cap: int) -> int:
+    """Byte offset of the tile_count section in the binning buffer (ggs_bin_layout section 1), memoised per problem shape."""
+    k = (prm.P, prm.W, prm.H, prm.n_views, cap)
+    r = _tc_off.get(k)
+    if r is None:
+        off = (C.c_size_t * 8)()
+        check(L.ggs_bin_layout(C.byref(prm), cap, off), "ggs_bin_layout")
+        r = _tc_off[k] = int(off[1])
+    return r
 
 
 def _workspace_sizes(L, prm, cap: int) -> Tuple[int, int, int]:
@@ -140,14 +163,15 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
         shs, colors_precomp, scales, rotations, cov3D_precomp = (
             None if (t is not None and t.numel() == 0) else t
             for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
+    # camera tensors and background left on the host are moved (the kernels would dereference host pointers otherwise: a GPU
+    # memory fault, not an exception); the reference keeps them on the device (scene/cameras.py ends every matrix in .cuda())
+    view, proj, campos, tanfov, bg = (t if t.device == dev else t.to(dev) for t in (view, proj, campos, tanfov, bg))
     view = _f32c(view).reshape(-1, 16)
     V = view.shape[0]
     proj = _f32c(proj).reshape(V, 16)
     campos = _f32c(campos).reshape(V, 3)
     tanfov = _f32c(tanfov).reshape(V, 2)
     bg = _f32c(bg)
-    if bg.device != dev:
-        bg = bg.to(dev)
     if bg.numel() == 3:
         bg = bg.reshape(1, 3) if V == 1 else bg.reshape(1, 3).expand(V, 3).contiguous()
     else:
@@ -210,6 +234,7 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
     if not capturing:
         _cap_hint[key] = max(cap if n * 2 <= cap else int(n * 2), 1 << 16)
     _last_header = _pinned.last_header = binb[:16].view(torch.int64)
+    _pinned.last_bin = (binb, V, ((W + 15) // 16) * ((H + 15) // 16), _tile_count_offset(L, prm, cap))
     if capturing:
         _capture_headers.append(_last_header)
     st = None

@@ -190,6 +190,20 @@ int ggs_photometric_forward_tab(int n_views, int H, int W, const float* img, con
 int ggs_photometric_backward_tab(int n_views, int H, int W, const float* img, const float* const* gt_tab,
                                  const float* const* mask_tab, const void* scratch, const float* weights, float* dL_dimg,
                                  void* stream);
+/* Region-of-interest form.  In the loops at s2_registration.py:252-267 / s3_appearance.py:125-140 the loss gradient exists
+ * only to be handed to the rasterizer's backward, and that reads dL/dimage on the pixels of tiles that have a splat list and
+ * nowhere else (for one 1080p view of the 100k-Gaussian garment: ~1 tile in 10).  `tile_count` = the list lengths of the
+ * forward that rendered `img` (section 1 of ggs_bin_layout: uint32 [n_views][ceil(H/16) * ceil(W/16)], device memory; NULL =
+ * the plain form).  With it the backward pass runs only the 64 x 12-pixel boxes that overlap a non-empty tile and leaves
+ * dL_dimg UNTOUCHED elsewhere, and the forward pass keeps the derivative maps of the boxes within reach of those; `sums` are the sums
+ * over all pixels, as in the plain form.  Images by plain pointers (gt, mask; tables NULL) or by tables (gt_tab, mask_tab;
+ * gt NULL), as above.  No reference counterpart (upstream composes the loss from PyTorch ops, utils/loss_utils.py:17-67). */
+int ggs_photometric_forward_roi(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
+                                const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count,
+                                float* sums, void* scratch, void* stream);
+int ggs_photometric_backward_roi(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
+                                 const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count,
+                                 const void* scratch, const float* weights, float* dL_dimg, void* stream);
 
 /*
  * Mean squared distance of every point to its 3 nearest neighbours (self excluded) -- replaces

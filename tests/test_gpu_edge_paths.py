@@ -190,3 +190,23 @@ def test_backward_never_reads_the_workspace_of_empty_tiles(n_views):
     for k in clean:
         assert torch.isfinite(dirty[k]).all(), k
         assert rel_l1(dirty[k], clean[k]) <= 1e-6, k
+
+
+def test_host_resident_camera_tensors_are_moved_not_dereferenced():
+    """Camera matrices left on the host (synthetic.rig_cameras() builds them there) used to reach the kernels as host pointers:
+    a GPU memory fault.  They are moved to the device like the background colour always was; same image either way."""
+    from types import SimpleNamespace
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    from ggsplat.render import render
+    v, f = S.skirt_mesh(20, 30)
+    m = MeshGaussianModel.from_tensors(v, f, S.skirt_gaussian_params(f.shape[0], 0), 0, device="cuda")
+    cam = S.rig_cameras(n_rings=1, n_az=4, width=160, height=120, f=130.0)[2]
+    assert cam.world_view_transform.device.type == "cpu"
+    pipe = SimpleNamespace(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+    with torch.no_grad():
+        m.update_face_coor()
+        on_host = render(cam, m, pipe, torch.zeros(3))["render"].clone()             # background on the host too
+        for n in ("world_view_transform", "full_proj_transform", "camera_center"):
+            setattr(cam, n, getattr(cam, n).cuda())
+        on_dev = render(cam, m, pipe, torch.zeros(3, device="cuda"))["render"]
+    assert float(on_host.abs().sum()) > 0 and torch.equal(on_host, on_dev)

@@ -94,3 +94,86 @@ def test_fused_loss_batched_views_and_1080p_speed():
     tf, tt = min(timed(fused) for _ in range(3)), min(timed(torch_ops) for _ in range(3))
     print(f"\\nphotometric loss fwd+bwd @1080p: fused {tf*1e3:.3f} ms, PyTorch ops {tt*1e3:.3f} ms ({tt/tf:.1f}x)")
     assert tf < tt
+
+
+@pytest.mark.parametrize("V,H,W,use_mask,density", [(1, 200, 330, True, 0.15), (2, 137, 130, False, 0.3), (1, 360, 640, True, 0.05),
+                                                   (3, 70, 33, True, 0.5), (1, 96, 128, False, 0.0), (1, 96, 128, True, 1.0)])
+def test_region_of_interest_form(V, H, W, use_mask, density):
+    """ggs_photometric_*_roi with the tile list lengths of a forward: the loss values are those of the plain form; dL/dimage is
+    the plain form's, bit for bit, on every pixel of a non-empty tile (all the rasterizer's backward ever reads) -- in fact in
+    every 64 x 12 box that overlaps one -- and the boxes that overlap none are not written at all."""
+    import ctypes as C
+    from ggsplat._lib import check, lib, ptr
+    L = lib()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(V * 1000 + H + W)
+    img, gt = torch.rand(V, 3, H, W, generator=g).to(dev), torch.rand(V, 3, H, W, generator=g).to(dev)
+    mask = (torch.rand(V, 1, H, W, generator=g) > 0.3).float().to(dev) if use_mask else None
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    tc = ((torch.rand(V, gy * gx, generator=g) < density).int() * 7).to(dev)
+    w = torch.tensor([[0.8, -0.2]] * V, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(tile_count):
+        sums = torch.empty(V, 2, device=dev)
+        scratch = torch.empty(L.ggs_photometric_scratch_bytes(V, H, W), device=dev, dtype=torch.uint8)
+        check(L.ggs_photometric_forward_roi(V, H, W, ptr(img), ptr(gt), ptr(mask), None, None, ptr(tile_count), ptr(sums),
+                                            ptr(scratch), stream), "fwd")
+        d = torch.full((V, 3, H, W), 123.0, device=dev)
+        check(L.ggs_photometric_backward_roi(V, H, W, ptr(img), ptr(gt), ptr(mask), None, None, ptr(tile_count), ptr(scratch),
+                                             ptr(w), ptr(d), stream), "bwd")
+        return sums, d
+
+    s_full, d_full = run(None)
+    s_roi, d_roi = run(tc)
+    assert float((s_full - s_roi).abs().max()) <= 1e-5 * float(s_full.abs().max())          # (atomic summation order)
+    assert not (d_full == 123.0).any()
+    # pixel masks: inside a non-empty tile; inside a box (64 columns x 12 rows) that overlaps a non-empty tile
+    tile_px = (tc.reshape(V, gy, gx) != 0).repeat_interleave(16, 1).repeat_interleave(16, 2)[:, :H, :W]
+    box = torch.zeros(V, H, W, dtype=torch.bool, device=dev)
+    for y0 in range(0, H, 12):
+        for x0 in range(0, W, 64):
+            hit = tile_px[:, y0:y0 + 12, x0:x0 + 64].reshape(V, -1).any(1)
+            box[:, y0:y0 + 12, x0:x0 + 64] = hit[:, None, None]
+    for ch in range(3):
+        a, b = d_roi[:, ch], d_full[:, ch]
+        assert torch.equal(a[box], b[box])                          # computed: identical to the plain form
+        assert (a[~box] == 123.0).all()                             # not computed: not written
+    assert bool((box | ~tile_px).all())                             # every pixel of a non-empty tile lies in an active box
+    if density == 0.0:
+        assert not box.any()
+    if density == 1.0:
+        assert box.all()
+
+
+def test_steps_with_the_region_of_interest_loss_give_the_same_gradients():
+    """registration_step(fused_loss=True) now takes the loss gradient only where the render backward reads it: every parameter
+    gradient equals the one obtained with the full dL/dimage (tile_count=None)."""
+    from types import SimpleNamespace
+    import ggsplat.inner_step as IS
+    from ggsplat import synthetic as S
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    W, H = 320, 200
+    v, f = S.skirt_mesh(30, 40)
+    params = S.skirt_gaussian_params(f.shape[0], sh_degree=0)
+    cam = S.rig_cameras(n_rings=1, n_az=4, width=W, height=H, f=260.0)[1]
+    gtr = torch.Generator().manual_seed(3)
+    gt = torch.rand(3, H, W, generator=gtr).cuda()
+    mask = (torch.rand(1, H, W, generator=gtr) > 0.2).float().cuda()
+    bg = torch.zeros(3, device="cuda")
+    grads = []
+    for roi in (True, False):
+        m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
+        m.training_setup(IS.DEFAULT_OPT, is_ff=True)
+        orig = IS.R.last_tile_count
+        if not roi:
+            IS.R.last_tile_count = lambda: None
+        try:
+            IS.registration_step(m, cam, gt, mask, bg, optimizer_step=False, fused_loss=True)
+        finally:
+            IS.R.last_tile_count = orig
+        grads.append({n: p.grad.clone() for n, p in zip(["mesh.v", "_xyz", "_f_dc", "_f_rest", "_opacity", "_scaling", "_rotation"],
+                                                        m.parameters()) if p.grad is not None})
+    assert set(grads[0]) == set(grads[1]) and len(grads[0]) >= 5
+    for k in grads[0]:
+        assert rel_l1(grads[0][k], grads[1][k]) <= 1e-6, k
