@@ -206,22 +206,13 @@ def main():
 
     def compute():
         """Everything of a step that runs on this GPU alone: mesh binding, fwd+bwd of this rank's views in launch sets
-        of `chunk`, gradient accumulation, mesh-binding backward.  Returns the parameter gradients."""
-        for p in plist:
-            p.grad = None
-        model.update_face_coor()
-        xyz, scaling, rot = model.get_xyz, model.get_scaling, model.get_rotation     # ONE fused HIP kernel
-        opacity, shs = model.get_opacity, model.get_features
-        inputs = dict(means3D=xyz.detach(), scales=scaling.detach(), rotations=rot.detach(),
-                      opacities=opacity.detach(), shs=shs.detach())
-        gr = batch.fwd_bwd_views(inputs, cams, bg=bg, W=W, H=H, sh_degree=args.sh_degree, chunk=chunk,
-                                 dL_dcolor_fn=lambda v0, v1, color: dL_buf[:v1 - v0])
-        torch.autograd.backward([xyz, scaling, rot, opacity, shs],
-                                [gr["means3D"], gr["scales"], gr["rotations"], gr["opacities"], gr["shs"]])
-        stats["num_rendered"] = gr["num_rendered"]
-        # the flat bucket [mesh.v | _xyz | f_dc | f_rest | opacity | scaling | rotation] is built here (one cat kernel,
-        # inside the captured graph); the step's all-reduce works on it directly and the per-tensor gradients are views
-        return flatten_grads([p.grad if p.grad is not None else torch.zeros_like(p) for p in plist])
+        of `chunk`, gradient accumulation, mesh-binding backward (ggsplat.batch.model_fwd_bwd_views: the C entry points
+        without the autograd graph).  Returns the flat gradient bucket [mesh.v | _xyz | f_dc | f_rest | opacity | scaling |
+        rotation] the step's all-reduce works on; the per-tensor gradients are views of it."""
+        r = batch.model_fwd_bwd_views(model, cams, bg=bg, W=W, H=H, chunk=chunk,
+                                      dL_dcolor_fn=lambda v0, v1, color: dL_buf[:v1 - v0])
+        stats["num_rendered"] = r["num_rendered"]
+        return r["flat"]
 
     graph = {"g": None, "grads": None, "headers": []}
 

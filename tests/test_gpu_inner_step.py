@@ -175,3 +175,40 @@ def test_render_python_paths_and_doll_render_on_gpu():
                   features=model.get_features, active_sh_degree=1)
         img, depth, alpha = doll_render(cam, doll, NS(debug=False), bg)
     assert torch.equal(img, base["render"]) and alpha.shape == (1, H, W) and depth.shape == (1, H, W)
+
+
+@pytest.mark.parametrize("sh_degree,bary", [(0, False), (2, True)])
+def test_model_fwd_bwd_views_matches_the_autograd_path(sh_degree, bary):
+    """ggsplat.batch.model_fwd_bwd_views (what bench.py's step runs: C entry points, no autograd graph) gives the gradient
+    bucket that autograd gives through the model's getters and the same multi-view render."""
+    from ggsplat import batch
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    Wd, Hd = 160, 96
+    v, f = S.skirt_mesh(24, 40, r_top=0.30, r_bottom=0.5, height=0.8, jitter=2e-3, seed=4)
+    params = S.skirt_gaussian_params(f.shape[0], sh_degree=sh_degree, seed=4)
+    g = torch.Generator().manual_seed(12)
+    bc = torch.rand(f.shape[0], 3, generator=g) + 0.05
+    m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=sh_degree, device="cuda",
+                                       gs_bc=(bc / bc.sum(1, keepdim=True)) if bary else None)
+    cams = S.stack_cameras(S.rig_cameras(n_rings=2, n_az=3, radius=2.2, width=Wd, height=Hd, f=120.0, seed=4), device="cuda")
+    bg = torch.zeros(3, device="cuda")
+    dL = torch.randn(6, 3, Hd, Wd, generator=g).cuda()
+    fn = lambda v0, v1, color: dL[v0:v1]
+    lean = batch.model_fwd_bwd_views(m, cams, bg=bg, W=Wd, H=Hd, chunk=4, dL_dcolor_fn=fn)["flat"]
+    plist = m.parameters()
+    for p in plist:
+        p.grad = None
+    m.update_face_coor()
+    xyz, scaling, rot, opacity, shs = m.get_xyz, m.get_scaling, m.get_rotation, m.get_opacity, m.get_features
+    gr = batch.fwd_bwd_views(dict(means3D=xyz.detach(), scales=scaling.detach(), rotations=rot.detach(), opacities=opacity.detach(),
+                                  shs=shs.detach()), cams, bg=bg, W=Wd, H=Hd, sh_degree=sh_degree, chunk=4, dL_dcolor_fn=fn)
+    torch.autograd.backward([xyz, scaling, rot, opacity, shs],
+                            [gr["means3D"], gr["scales"], gr["rotations"], gr["opacities"], gr["shs"]])
+    ref = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in plist])
+    assert lean.shape == ref.shape and float(ref.abs().sum()) > 0
+    o = 0
+    for p in plist:
+        n = p.numel()
+        if n and float(ref[o:o + n].abs().sum()) > 0:
+            assert rel_l1(lean[o:o + n], ref[o:o + n]) <= 2e-6, (o, n)
+        o += n
