@@ -182,7 +182,7 @@ def main():
 
     from ggsplat import batch, synthetic as S
     from ggsplat import _lib
-    from ggsplat.dist import all_reduce_bucket, bucket_views, flatten_grads, shard_views
+    from ggsplat.dist import all_reduce_bucket, bucket_views, shard_views
     from ggsplat.mesh_gaussian_model import MeshGaussianModel
     import ctypes as C
 
