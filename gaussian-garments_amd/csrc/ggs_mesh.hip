@@ -169,11 +169,22 @@ __global__ __launch_bounds__(256) void k_mesh_fwd(MeshArgs a) {
 }
 
 // Vertex gradients: the 256 Gaussians of a workgroup are neighbours on the mesh, so the vertices they touch usually span a
-// short index range.  Their 9 contributions each are summed in an LDS window over that range (ds_add_f32) and the window is
+// short index range.  Their 9 contributions each are summed in an LDS window over that range (lds_add_f32 below) and the window is
 // flushed with ONE global atomic per touched component: 100k Gaussians on a 50k-vertex grid send ~0.9 M global atomics with
 // ~6 writers per address otherwise, which was this kernel's whole duration (30 us; the arithmetic is ~3 us).  A range
 // wider than the window (unstructured bindings) falls back to the direct atomics.
 #define MESH_WIN 2048            // vertices -> 24 KB of LDS
+// LDS float add as a compare-and-swap loop: gfx950 executes ds_add_f32 one lane every ~3 cycles per CU (770 cycles per
+// wave-instruction whatever the addresses; the integer ds_add_u32 takes 17), and a ds_cmpst loop measures 40-180 cycles per
+// wave-instruction (tools/ubench/lds_atomics.hip, profiles/r04_lds_atomic_rates.md).
+__device__ __forceinline__ void lds_add_f32(float* p, float v) {
+    unsigned* u = reinterpret_cast<unsigned*>(p);
+    unsigned old = *u, assumed;
+    do {
+        assumed = old;
+        old = atomicCAS(u, assumed, __float_as_uint(__uint_as_float(assumed) + v));
+    } while (old != assumed);
+}
 __global__ __launch_bounds__(256) void k_mesh_bwd(MeshArgs a) {
     __shared__ float s_win[MESH_WIN * 3];
     __shared__ int s_rng[2];
@@ -296,9 +307,9 @@ __global__ __launch_bounds__(256) void k_mesh_bwd(MeshArgs a) {
             float* o0 = s_win + 3 * (int)(idx[0] - vbase);
             float* o1 = s_win + 3 * (int)(idx[1] - vbase);
             float* o2 = s_win + 3 * (int)(idx[2] - vbase);
-            atomicAdd(o0, g0.x); atomicAdd(o0 + 1, g0.y); atomicAdd(o0 + 2, g0.z);
-            atomicAdd(o1, g1.x); atomicAdd(o1 + 1, g1.y); atomicAdd(o1 + 2, g1.z);
-            atomicAdd(o2, g2.x); atomicAdd(o2 + 1, g2.y); atomicAdd(o2 + 2, g2.z);
+            lds_add_f32(o0, g0.x); lds_add_f32(o0 + 1, g0.y); lds_add_f32(o0 + 2, g0.z);
+            lds_add_f32(o1, g1.x); lds_add_f32(o1 + 1, g1.y); lds_add_f32(o1 + 2, g1.z);
+            lds_add_f32(o2, g2.x); lds_add_f32(o2 + 1, g2.y); lds_add_f32(o2 + 2, g2.z);
         }
         __syncthreads();
         float* out = a.dL_dverts + 3 * (size_t)vbase;

@@ -60,6 +60,78 @@ __device__ __forceinline__ float fold_rows(float q1, float q2, float r5) {
     return q1;
 }
 
+// ---- wave reduction through an LDS transpose (GGS_BWD_RED = 1, the default) ------------------------
+// The butterfly above spends ~105 VALU-issue cycles per list entry, most of them in v_permlane32/16_swap (8.3 cycles each).
+// Here eight of the values cross the lanes through a wave-private LDS plane instead: every lane stores its 8 partials
+// (plane [value][80] floats: bank = lane mod 32, conflict-free), then lane 8 v + s reads back the 8 partials
+// {2 s, 2 s + 1} + 16 k of value v (4 x ds_read_b64: bank = (16 v + 2 s) mod 64 within each half-wave, conflict-free), adds
+// them (7 v_add_f32) and three DPP adds inside its 8-lane group finish the sum: 10 VALU instructions for 8 values, the LDS pipe
+// issues beside the VALU.  The ninth value (and the tenth with depth / alpha gradients) stays on a DPP chain that ends in
+// lanes the eight groups do not need: every total sits in its own lane of ONE register, as before (one vector atomic).
+//   result lanes: 8 v -> value v (v = 0..7);  !DA: lane 63 -> value 8;  DA: lane 31 -> value 8, lane 63 -> value 9
+// Measured (profiles/r04_bwd_variants.md): ggs_k_render_bwd 42.2 -> 38.7 us per view; with the DS instructions the compiler
+// picks from plain C++ (ds_write2_b32 pairs, ds_read2_b64) 39.7; a what-if build with NO reduction at all: 31.0.
+#define GGS_RED_STRIDE 80
+template <bool DA>
+__device__ __forceinline__ float lds_transpose_reduce(float* s_red, int lane, float v0, float v1, float v2, float v3,
+                                                      float v4, float v5, float v6, float v7, float v8, float v9) {
+    // The LDS side is written out: ds_write_addtid_b32 (address = M0 + offset + 4 lane, no address VGPR: 2 cycles of the
+    // VGPR -> LDS path per instruction against 4 for ds_write_b32 / 6 for the ds_write2_b32 pairs the compiler forms) and four
+    // plain ds_read_b64 (2 LDS cycles each; the compiler merges them into two ds_read2_b64 of 8).  The waits are explicit:
+    // the compiler's own lgkmcnt bookkeeping stays conservative with extra DS operations in flight (they return in order).
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f a, b, c, d;
+    const unsigned base = (unsigned)(uintptr_t)s_red;
+    const unsigned rd = base + ((lane >> 3) * GGS_RED_STRIDE + (lane & 7) * 2) * 4;
+    asm volatile("s_mov_b32 m0, %8\n\t"
+                 "s_nop 0\n\t"
+                 "ds_write_addtid_b32 %0\n\t"
+                 "ds_write_addtid_b32 %1 offset:320\n\t"
+                 "ds_write_addtid_b32 %2 offset:640\n\t"
+                 "ds_write_addtid_b32 %3 offset:960\n\t"
+                 "ds_write_addtid_b32 %4 offset:1280\n\t"
+                 "ds_write_addtid_b32 %5 offset:1600\n\t"
+                 "ds_write_addtid_b32 %6 offset:1920\n\t"
+                 "ds_write_addtid_b32 %7 offset:2240"
+                 :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "s"(base) : "memory", "m0");
+    asm volatile("ds_read_b64 %0, %4\n\t"
+                 "ds_read_b64 %1, %4 offset:64\n\t"
+                 "ds_read_b64 %2, %4 offset:128\n\t"
+                 "ds_read_b64 %3, %4 offset:192"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(rd) : "memory");
+    // the ninth / tenth value: in-row DPP sums while the LDS reads are in flight
+    float t = DA ? swap32_add(v8, v9) : v8;           // DA: lanes 0-31 partials of v8, lanes 32-63 of v9
+    t += dpp_fetch<0xB1, 0xf>(t);                     // quad_perm:[1,0,3,2]
+    t += dpp_fetch<0x4E, 0xf>(t);                     // quad_perm:[2,3,0,1]
+    t += dpp_fetch<0x141, 0xf>(t);                    // row_half_mirror
+    t += dpp_fetch<0x140, 0xf>(t);                    // row_mirror: every lane holds its row total
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    float s = ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y));
+    s += dpp_fetch<0xB1, 0xf>(s);
+    s += dpp_fetch<0x4E, 0xf>(s);
+    s += dpp_fetch<0x141, 0xf>(s);                    // every lane of group v holds the total of value v
+    if (DA) {        // rows 1 / 3 <- rows 0 + 1 / 2 + 3, then lanes 28-31 / 60-63 of s take them
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_mov_b32_dpp %1, %0 quad_perm:[0,1,2,3] row_mask:0xa bank_mask:0x8" : "+v"(t), "+v"(s));
+    } else {         // row 1 / 3 <- + row 0 / 2, then lanes 60-63 of s <- lane 31 + own = the wave total
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_f32_dpp %1, %0, %0 row_bcast:31 row_mask:0x8 bank_mask:0x8" : "+v"(t), "+v"(s));
+    }
+    return s;
+}
+// GradRec field the lane adds to after lds_transpose_reduce (-1: none)
+template <bool DA>
+__device__ __forceinline__ int lds_reduce_field(int lane) {
+    if ((lane & 7) == 0) return lane >> 3;
+    if (lane == 63) return DA ? 9 : 8;
+    if (DA && lane == 31) return 8;
+    return -1;
+}
+
 // Lane selects driven by explicit 64-bit lane masks.  The forward keeps its predicates (alpha test, stop, blend) as
 // SGPR masks so that their population counts run on the scalar unit; going through `bool` the compiler rebuilds a
 // mask from a 0/1 VGPR (v_cndmask + v_cmp) every time a ballot of a combined predicate is needed.

@@ -319,11 +319,22 @@ class GraphedRegistrationStep:
             self._hdr_dev = R.last_header()
             torch.add(self._hdr_dev, 0, out=self._out[32:48].view(torch.int64))   # next to the statistics: one read-back
         self.out = {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
+        self._captured = self._identity()
+
+    def _identity(self):
+        """The tensors whose ADDRESSES a captured step holds: parameters, mesh connectivity, binding, statistics.  Density
+        control (ggsplat.densify) and load_ply replace them with new tensors of another size; the next call re-captures."""
+        g = self.g
+        ts = list(g.parameters()) + [g.mesh.f, g.binding, g.gs_bc, g.max_radii2D, g.xyz_gradient_accum, g.denom]
+        return tuple((id(t), None if t is None else t.data_ptr(), None if t is None else tuple(t.shape)) for t in ts)
 
     def __call__(self, cam, gt_image, mask=None) -> Dict[str, torch.Tensor]:
         """One optimisation step.  Returns {"loss", "img", "ssim", ...}: Python floats (lean) or device scalars that the
         next call overwrites (lean=False)."""
         self._load(cam, gt_image, mask)
+        if self.graph is not None and self._captured != self._identity():
+            self.graph = None                       # P changed under the graph (densify / prune): capture the new shapes
+            self.recaptures += 1
         if self.graph is None:
             self._capture()
             # the capture itself does not execute anything: fall through to the first replay

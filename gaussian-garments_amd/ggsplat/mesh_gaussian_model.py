@@ -15,8 +15,9 @@ rotation together, and its backward scatters straight into mesh.v.grad.  The res
 per update_face_coor() call, so the three getters cost nothing extra.
 
 Persistence: save_ply / load_ply in the reference's PLY layout incl. binding.pkl, OBJ mesh IO
-(ggsplat.mesh_io).  Densify / prune and LBS are out of scope; the model is built from tensors (``from_tensors``) or
-from a stage-2 directory (load_mesh + load_ply).
+(ggsplat.mesh_io).  Adaptive density control (densify_and_prune, prune_points, densify_and_split / _clone with binding
+inheritance and optimiser-state surgery, scene/mesh_gaussian_model.py:130-208) lives in ggsplat.densify.  LBS is out of
+scope; the model is built from tensors (``from_tensors``) or from a stage-2 directory (load_mesh + load_ply).
 """
 from __future__ import annotations
 
@@ -28,6 +29,7 @@ import torch
 from torch import nn
 
 from ._lib import check, lib, ptr
+from .densify import DensifyMixin
 
 
 def _stream(dev):
@@ -111,7 +113,7 @@ def _version_of(t):
         return -1
 
 
-class MeshGaussianModel:
+class MeshGaussianModel(DensifyMixin):
     def __init__(self, sh_degree: int):
         self.active_sh_degree = 0
         self.max_sh_degree = sh_degree
@@ -146,6 +148,8 @@ class MeshGaussianModel:
         for k in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity"):
             setattr(m, k, nn.Parameter(params[k].to(device).float().contiguous()))
         m.binding = params["binding"].to(device).long().contiguous()
+        # Gaussians per face (scene/mesh_gaussian_model.py:83): pruning never empties a face
+        m.binding_counter = torch.bincount(m.binding, minlength=m.mesh.f.shape[0]).to(torch.int32)
         m.max_radii2D = torch.zeros(m._xyz.shape[0], device=device)
         if gs_bc is not None:
             m.gs_bc = gs_bc.to(device).float().contiguous()      # [P,3]

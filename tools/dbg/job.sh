@@ -1,0 +1,36 @@
+#!/bin/bash
+# job.sh STEP [STEP ...] -- the GPU-box jobs of a round as ONE parameterised script (replaces the per-experiment r3_*.sh files).
+# Run through gpurun from the repo root:  gpurun --timeout 900 -- 'bash tools/dbg/job.sh ubench_lds census ab'
+# Every step writes under gpurun_out/ (merged back by gpurun).  Environment: TAG (file-name prefix, default r04),
+# TESTS (pytest selection for `partests`), LIBS (variant names for `ab` / `partests`, default: all of csrc/variants/*.so),
+# BENCH_ARGS (extra bench.py flags for `ab`).
+cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
+export TMPDIR=/tmp
+TAG=${TAG:-r04}
+OUT=gpurun_out
+mkdir -p $OUT
+VAR=gaussian-garments_amd/csrc/variants
+libs() { if [ -n "$LIBS" ]; then for l in $LIBS; do echo $VAR/$l.so; done; else ls $VAR/*.so; fi; }
+for step in "$@"; do
+  echo "=== $step ==="
+  case $step in
+    ubench_lds)      # LDS float-atomic rates + the transposed-reduction block (tools/ubench/lds_atomics.hip)
+      (cd tools/ubench && timeout 300 ./lds_atomics) > $OUT/${TAG}_lds_atomics.txt 2>&1; tail -45 $OUT/${TAG}_lds_atomics.txt ;;
+    ubench_systolic) (cd tools/ubench && timeout 300 ./systolic_parts) > $OUT/${TAG}_systolic_parts.txt 2>&1; tail -40 $OUT/${TAG}_systolic_parts.txt ;;
+    census)          timeout 600 python tools/dbg/fold_census.py > $OUT/${TAG}_fold_census.txt 2>&1; cat $OUT/${TAG}_fold_census.txt ;;
+    partests)        # parity tests against a variant library
+      for f in $(libs); do echo "--- $f"; GGS_LIB_PATH=$PWD/$f timeout 1500 python -m pytest ${TESTS:-tests/test_gpu_parity.py tests/test_gpu_fullsize.py} -x -q 2>&1 | tail -8; done > $OUT/${TAG}_partests.txt 2>&1; cat $OUT/${TAG}_partests.txt ;;
+    ab)              # interleaved A/B timing of library builds (three runs each), per-kernel us / view
+      for rep in 1 2 3; do for f in $(libs); do
+        echo -n "$(basename $f) rep $rep: "
+        GGS_LIB_PATH=$PWD/$f timeout 600 python bench.py --steps 30 --warmup 3 --cpu-views 0 --loop-views 0 --extra-configs 0 $BENCH_ARGS 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_launch']; print(d['value'], {a: round(b / d['roofline']['launch_views'] * 1e3, 2) for a, b in k.items()})"
+      done; done > $OUT/${TAG}_ab.txt 2>&1; cat $OUT/${TAG}_ab.txt ;;
+    prof)            # rocprofv3 passes of tools/profile_all.sh for each variant library: PASSES (default "sq lds"), PROF_ARGS (bench flags)
+      for f in $(libs); do n=$(basename $f .so); GGS_LIB_PATH=$PWD/$f PASSES="${PASSES:-sq lds}" bash tools/profile_all.sh ${TAG}_$n $PROF_ARGS > $OUT/${TAG}_prof_$n.log 2>&1
+        cat $OUT/prof_${TAG}_${n}_sq_counters.md $OUT/prof_${TAG}_${n}_lds_counters.md 2>/dev/null | grep -v "^$"; done ;;
+    gputests)        timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/${TAG}_gputests.txt; cat $OUT/${TAG}_gputests.txt ;;
+    bench)           timeout 900 python bench.py $BENCH_ARGS > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; cat $OUT/${TAG}_bench.json ;;
+    *) echo "unknown step $step" ;;
+  esac
+done

@@ -3,6 +3,7 @@
 #   [WORKLOAD="P W H sh_degree"] [PASSES="trace sq valu fetch write"] tools/profile_all.sh TAG [bench.py workload flags, e.g. --sh-degree 3]
 #   trace  kernel trace (rocprofv3 --kernel-trace --stats) of `bench.py --steps 3 --warmup 1`    -> gpurun_out/TAG_trace
 #   sq     SQ instruction / wave-cycle counters (one --pmc pass, kernel-trace only)               -> gpurun_out/TAG_sq
+#   lds    LDS pipe: instructions, busy / stall / bank-conflict cycles (one --pmc pass)
 #   valu   VALU busy / lane activity: raw counters, then rocprofv3's derived VALUBusy / VALUUtilization (two --pmc passes)
 #   fetch, write   FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slots; MI355X_MICROARCH.md, HBM section)
 # No other tracing domain is ever combined with --pmc.  The build id of the library is recorded beside the results;
@@ -31,12 +32,13 @@ for p in $PASSES; do
     sq)    pmc_pass sq SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU ;;
     valu)  pmc_pass valu SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES
            pmc_pass valud VALUBusy VALUUtilization ;;
+    lds)   pmc_pass lds SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES ;;
     fetch) pmc_pass fetch FETCH_SIZE ;;
     write) pmc_pass write WRITE_SIZE ;;
   esac
 done
 # summarise on the box and drop the databases: the merge back into gpurun_out/ is capped at 64 MiB
 python $R/tools/profile_summary.py $TAG $R/gpurun_out/prof_${TAG} $WORKLOAD || true
-rm -rf ${OUT}_trace ${OUT}_sq ${OUT}_valu ${OUT}_valud ${OUT}_fetch ${OUT}_write
+rm -rf ${OUT}_trace ${OUT}_sq ${OUT}_lds ${OUT}_valu ${OUT}_valud ${OUT}_fetch ${OUT}_write
 for f in ${OUT}_*.log; do tail -5 $f > $f.tail; rm -f $f; done
 ls -la $R/gpurun_out | grep ${TAG} | head -20

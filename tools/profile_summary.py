@@ -49,6 +49,31 @@ def sq_table(path, out, header):
                     f"{g('SQ_ACTIVE_INST_VALU') / max(g('SQ_INSTS_VALU'), 1):.2f} | {dur.get(k, 0):.0f} |\n")
 
 
+def lds_table(path, out, header):
+    """LDS pipe counters per kernel (profile_all.sh pass `lds`): instructions, busy / stall / bank-conflict cycles."""
+    cur = sqlite3.connect(path).cursor()
+    rows = {}
+    for name, counter, n, total in cur.execute(
+            "select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
+        m = re.match(r"(ggs_k_\w+)", name)
+        if m:
+            rows.setdefault(m.group(1), {})[counter] = (n, total)
+    with open(out, "w") as f:
+        f.write(header)
+        f.write("| kernel | waves / launch | LDS instr / wave | ACTIVE_INST_LDS % of wave-cycles | WAIT_INST_LDS % | LDS_IDX_ACTIVE / LDS instr | "
+                "BANK_CONFLICT / LDS_IDX_ACTIVE % | LDS_IDX_ACTIVE / BUSY_CYCLES % |\n|---|---|---|---|---|---|---|---|\n")
+        for k, c in sorted(rows.items()):
+            g = lambda n: c.get(n, (1, 0.0))[1]
+            launches = c["SQ_WAVES"][0]
+            waves = max(g("SQ_WAVES"), 1.0)
+            wc = max(g("SQ_WAVE_CYCLES"), 1.0)
+            li = max(g("SQ_INSTS_LDS"), 1.0)
+            idx = max(g("SQ_LDS_IDX_ACTIVE"), 1.0)
+            f.write(f"| {k} | {waves / launches:.0f} | {li / waves:.1f} | {100 * g('SQ_ACTIVE_INST_LDS') / wc:.1f} | "
+                    f"{100 * g('SQ_WAIT_INST_LDS') / wc:.1f} | {idx / li:.2f} | {100 * g('SQ_LDS_BANK_CONFLICT') / idx:.1f} | "
+                    f"{100 * idx / max(g('SQ_BUSY_CYCLES'), 1.0):.1f} |\n")
+
+
 def valu_table(path, prefix, bid, bargs, workload, derived_path=None):
     """VALUBusy = 100 sum(SQ_ACTIVE_INST_VALU) / CU_NUM / max(GRBM_GUI_ACTIVE) and VALUUtilization = 100 sum(SQ_THREAD_CYCLES_VALU)
     / (sum(SQ_ACTIVE_INST_VALU) 64) -- rocprofiler-sdk's own gfx950 formulas (counter_defs.yaml), evaluated per kernel."""
@@ -108,6 +133,12 @@ def main(tag, prefix, workload):
         sq_table(s, prefix + "_sq_counters.md",
                  f"# SQ counters (rocprofv3 --pmc, one pass, kernel-trace only), build {bid}\n\n`python bench.py --cpu-views 0 "
                  f"--loop-views 0 --extra-configs 0 {bargs} --steps 1 --warmup 0 --views 32`; wave-cycle counters are in quad-cycles.\n\n")
+    l = db(tag, "lds")
+    if l:
+        lds_table(l, prefix + "_lds_counters.md",
+                  f"# LDS counters (rocprofv3 --pmc, one pass, kernel-trace only), build {bid}\n\n`python bench.py --cpu-views 0 "
+                  f"--loop-views 0 --extra-configs 0 {bargs} --steps 1 --warmup 0 --views 32`; SQ cycle counters are in quad-cycles, "
+                  f"summed over the SQs they are collected on.\n\n")
     u = db(tag, "valu")
     if u:
         valu_table(u, prefix, bid, bargs, workload, db(tag, "valud"))

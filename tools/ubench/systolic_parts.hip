@@ -103,7 +103,7 @@ int main() {
     float* d_f; CHECK(hipMalloc(&d_f, 4096));
     const char* names[8] = {"v_mov_b32_dpp row_ror:1", "ds_add_f32 (per-lane addresses, stride 17 words)", "ds_read_b128 (per-lane, stride 48 B)", "4 v_fma + 1 ds_add_f32 (per group)", "v_add_f32_dpp x, 0 row_ror:1", "v_mov_b32_dpp other dst row_ror:1", "v_mov_b32_dpp row_shr:1 bound_ctrl", "v_mov_b32_dpp quad_perm"};
     for (int K = 0; K < 8; ++K) {
-        if (K == 1 || K == 3) continue;   // ds_add_f32: ~800 cycles per instruction (measured once; skipped)
+        // K == 1 / 3 (ds_add_f32): also measured case by case in tools/ubench/lds_atomics.hip (profiles/r04_lds_atomic_rates.md)
         for (int w : {1, 2, 4}) {
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             auto launch = [&] {
