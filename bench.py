@@ -65,6 +65,10 @@ def parse():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every step eagerly instead of replaying the captured hipGraph of its compute part")
+    ap.add_argument("--overlap", type=int, default=0, metavar="PARTS",
+                    help="N > 1: a rank's views are rendered in PARTS slices and slice i is all-reduced (asynchronously, RCCL's own "
+                         "stream) while slice i + 1 is computed: only the last slice's collective stays exposed (ggsplat.dist."
+                         "all_reduce_parts).  0 / 1: one all-reduce of the whole bucket behind the compute")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl == RCCL on ROCm; gloo for functional tests)")
     ap.add_argument("--dump-grads", default="", help="rank 0 saves the step's (all-reduced) flat gradient bucket to this .pt file")
     ap.add_argument("--single-device", action="store_true",
@@ -182,7 +186,7 @@ def main():
 
     from ggsplat import batch, synthetic as S
     from ggsplat import _lib
-    from ggsplat.dist import all_reduce_bucket, bucket_views, shard_views
+    from ggsplat.dist import all_reduce_bucket, all_reduce_parts, bucket_views, shard_views
     from ggsplat.mesh_gaussian_model import MeshGaussianModel
     import ctypes as C
 
@@ -204,45 +208,58 @@ def main():
     plist = model.parameters()
     stats = {}
 
-    def compute():
-        """Everything of a step that runs on this GPU alone: mesh binding, fwd+bwd of this rank's views in launch sets
-        of `chunk`, gradient accumulation, mesh-binding backward (ggsplat.batch.model_fwd_bwd_views: the C entry points
-        without the autograd graph).  Returns the flat gradient bucket [mesh.v | _xyz | f_dc | f_rest | opacity | scaling |
-        rotation] the step's all-reduce works on; the per-tensor gradients are views of it."""
-        r = batch.model_fwd_bwd_views(model, cams, bg=bg, W=W, H=H, chunk=chunk,
+    # --overlap PARTS: the rank's views in PARTS contiguous slices, each with its own captured graph and its own bucket
+    n_parts = max(1, min(args.overlap, len(my))) if world > 1 or args.overlap > 1 else 1
+    bounds = [round(i * len(my) / n_parts) for i in range(n_parts + 1)]
+    part_cams = [{k: v[bounds[i]:bounds[i + 1]] for k, v in cams.items()} for i in range(n_parts)]
+
+    def compute(part=0):
+        """Everything of a step that runs on this GPU alone, for one slice of this rank's views: mesh binding, fwd+bwd of
+        the slice in launch sets of `chunk`, gradient accumulation, mesh-binding backward (ggsplat.batch.model_fwd_bwd_views:
+        the C entry points without the autograd graph).  Returns the flat gradient bucket [mesh.v | _xyz | f_dc | f_rest |
+        opacity | scaling | rotation] the step's all-reduce works on; the per-tensor gradients are views of it."""
+        r = batch.model_fwd_bwd_views(model, part_cams[part], bg=bg, W=W, H=H, chunk=chunk,
                                       dL_dcolor_fn=lambda v0, v1, color: dL_buf[:v1 - v0])
-        stats["num_rendered"] = r["num_rendered"]
+        stats["num_rendered"] = r["num_rendered"] + (stats.get("num_rendered", 0) if part else 0)
         return r["flat"]
 
-    graph = {"g": None, "grads": None, "headers": []}
+    graph = {"g": None, "grads": None, "headers": []}            # g / grads: one entry per slice when captured
+
+    def part_bucket(i):
+        if graph["g"] is not None:
+            graph["g"][i].replay()
+            return graph["grads"][i]
+        return compute(i)
 
     def step():
         # The compute part is captured once into a hipGraph (no host sync inside: the rasterizer runs with the binning
         # capacity the eager warm-up learnt and leaves its overflow word on the device) and replayed; the gradient
         # all-reduce stays outside.  At 8 GPUs a rank's step is ~2 ms, and the eager launches + the header read-back
         # per launch set were ~7 % of it.
-        if graph["g"] is not None:
-            graph["g"].replay()
-            flat = graph["grads"]
-        else:
-            flat = compute()
-        all_reduce_bucket(flat)                   # ONE RCCL call per step, nothing else around it
+        if n_parts == 1:
+            flat = part_bucket(0)
+            all_reduce_bucket(flat)               # ONE RCCL call per step, nothing else around it
+        else:                                     # slice i summed over the ranks while slice i + 1 renders
+            flat = all_reduce_parts([(lambda i=i: part_bucket(i)) for i in range(n_parts)])
         stats["grads"] = bucket_views(flat, plist)
 
     def capture():
         from ggsplat import rasterizer as R
         R.pop_capture_headers()
-        g = torch.cuda.CUDAGraph()
+        gs, grads = [], []
         try:
-            # thread_local: API calls of other threads (the RCCL watchdog polling its events) cannot invalidate the capture
-            with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                grads = compute()
+            for i in range(n_parts):
+                g = torch.cuda.CUDAGraph()
+                # thread_local: API calls of other threads (the RCCL watchdog polling its events) cannot invalidate the capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    grads.append(compute(i))
+                gs.append(g)
         except Exception as e:                   # stay on the eager launches (same kernels) rather than fail the run
             print(f"[bench] graph capture failed ({type(e).__name__}: {e}); launching eagerly", file=sys.stderr, flush=True)
             torch.cuda.synchronize(dev)
             R.pop_capture_headers()
             return
-        graph.update(g=g, grads=grads, headers=R.pop_capture_headers())
+        graph.update(g=gs, grads=grads, headers=R.pop_capture_headers())
 
     def sync():
         if world > 1:
@@ -611,6 +628,10 @@ def main():
                                    f"{W}x{H} cameras, SH degree {args.sh_degree}, fwd+bwd with dense dL/dimage",
                        "views_per_step": n_views_total, "views_per_launch": chunk, "parallelism": f"views sharded x{world}",
                        "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
+                       # gradient exchange: slices per rank (1 = one all-reduce behind the compute); with one rank there is no
+                       # collective and no scaling curve in this line
+                       "all_reduce_parts": n_parts, "collective": "none (one rank)" if world == 1 else
+                       ("one all-reduce per step" if n_parts == 1 else f"{n_parts} all-reduces per step, all but the last overlapped with compute"),
                        "ranks": ranks_seen,
                        "num_rendered_per_view": round(N_view, 1), "visible_per_view": round(P_vis, 1),
                        "mean_list_length_per_tile": round(N_view / T, 2),
@@ -623,6 +644,11 @@ def main():
             # config-4 FORM of the s3 iteration (texel-bound Gaussians, K = 16, vis mask, five-term loss, Adam) with a two-tensor
             # stand-in for the StyleUNet: a rasterizer + loss + optimiser number, not a config-4 number
             "s3_graph_step_standin_net_iters_per_sec": None if s3_vps is None else round(s3_vps, 2),
+            # how the four loop figures above are measured (unchanged since round 3; rounds 1-2 timed ONE pass over 16 views
+            # against a random ground-truth image, so their figures are not comparable one to one)
+            "loop_timing": None if loop_vps is None else {
+                "views": args.loop_views, "passes": "one untimed pass, then the better of two timed passes over the same views",
+                "ground_truth": "the initial model's own render of each camera + N(0, 0.02) noise, mask ~90 % ones"},
         }
         print(json.dumps(out), flush=True)
     if world > 1:

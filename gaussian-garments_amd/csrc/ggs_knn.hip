@@ -108,16 +108,29 @@ __global__ __launch_bounds__(64) void k_knn_setup(int P, int n_partial, KnnWs w)
     if (threadIdx.x != 0) return;
     float e[3], emax = 0.f;
     for (int a = 0; a < 3; ++a) { e[a] = hi[a] - lo[a]; emax = fmaxf(emax, e[a]); }
-    if (!(emax > 0.f) || !(emax < 3.0e38f)) emax = 1.f;                    // all points equal (or non-finite input): one cell
+    // all points equal, or a non-finite coordinate (inf - inf = NaN, inf extents): ONE cell -- the search then degenerates to the
+    // exhaustive scan, which returns garbage for garbage input like the brute-force kernel does, instead of an index fault
+    bool finite = true;
+    for (int a = 0; a < 3; ++a) finite = finite && (e[a] >= 0.f) && (e[a] < 3.0e38f) && (lo[a] > -3.0e38f) && (hi[a] < 3.0e38f);
+    if (!finite) { for (int a = 0; a < 3; ++a) { e[a] = 0.f; lo[a] = 0.f; } emax = 0.f; }
+    if (!(emax > 0.f)) emax = 1.f;
     for (int a = 0; a < 3; ++a) e[a] = fmaxf(e[a], emax * 1e-6f);
     float target = fminf(2.f * (float)P, (float)w.ncell_max);
     float h = cbrtf(e[0] * e[1] * e[2] / target);
     int n[3];
     for (int it = 0; it < 4; ++it) {
         double prod = 1.0;
-        for (int a = 0; a < 3; ++a) { float f = floorf(e[a] / h); n[a] = f < 1.f ? 1 : (f > 1024.f ? 1024 : (int)f); prod *= n[a]; }
+        // !(f >= 1): also catches NaN (a NaN would pass both clamps and convert to 0 cells)
+        for (int a = 0; a < 3; ++a) { float f = floorf(e[a] / h); n[a] = !(f >= 1.f) ? 1 : (f > 1024.f ? 1024 : (int)f); prod *= n[a]; }
         if (prod <= (double)w.ncell_max) break;
         h *= cbrtf((float)(prod / (double)w.ncell_max)) * 1.02f;
+    }
+    // Degenerate extents (planar / linear clouds: an axis pinned at the 1024-cell clamp keeps the product from shrinking with
+    // h): grow h until the clamped grid fits, recomputing n after EVERY rescale, instead of giving up on the grid (one cell =
+    // an O(P^2) scan per lane).
+    for (int it = 0; it < 64 && (double)n[0] * n[1] * n[2] > (double)w.ncell_max; ++it) {
+        h *= 1.26f;
+        for (int a = 0; a < 3; ++a) { float f = floorf(e[a] / h); n[a] = !(f >= 1.f) ? 1 : (f > 1024.f ? 1024 : (int)f); }
     }
     if ((double)n[0] * n[1] * n[2] > (double)w.ncell_max) { n[0] = n[1] = n[2] = 1; }
     // cells of size h starting at lo; the last cell of an axis absorbs the remainder (cell index is clamped)

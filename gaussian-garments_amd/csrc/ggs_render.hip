@@ -36,7 +36,7 @@
 #ifndef GGS_BWD_SADDR
 #define GGS_BWD_SADDR 1
 #endif
-// GGS_WHATIF_NORED / GGS_WHATIF_NOREC: what-if builds with WRONG results (no reduction / record fields fabricated on the scalar
+// GGS_WHATIF_NORED / GGS_WHATIF_NOREC / GGS_WHATIF_SKIPRED: what-if builds with WRONG results (no reduction / record fields fabricated on the scalar
 // unit) that price a stage by removing it; never the product library.
 
 #include "ggs_render_common.h"
@@ -373,7 +373,9 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
         B[q] = T[q] * (bg0 * dC0[q] + bg1 * dC1[q] + bg2 * dC2[q]);
     }
     // GradRec field this lane adds to after the reduction (fold_rows): first lane of quad 0 / 2 / 1 of each row
-#if GGS_BWD_RED >= 1
+#if GGS_BWD_RED == 2
+    const int fld = lds_reduce16_field<DA>(lane);
+#elif GGS_BWD_RED == 1
     const int fld = lds_reduce_field<DA>(lane);
 #else
     const int row = lane >> 4, quad = (lane >> 2) & 3;
@@ -393,7 +395,9 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
 
     __shared__ float4 s_rec[64 * 3];
     RoundLds lds{s_rec};
-#if GGS_BWD_RED >= 1
+#if GGS_BWD_RED == 2
+    __shared__ float s_red[10 * GGS_RED16_STRIDE];
+#elif GGS_BWD_RED == 1
     __shared__ float s_red[8 * GGS_RED_STRIDE];
 #endif
 #if GGS_BWD_ZERO_LDS
@@ -426,7 +430,9 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
             // recurrence is sequential (A = the entry further back, then B).
             auto reduce_add = [&](uint32_t word, float v_mx, float v_my, float v_cx, float v_cy, float v_cz, float v_op,
                                   float v_r, float v_g, float v_b, float v_dep) {
-#if GGS_BWD_RED >= 1
+#if GGS_BWD_RED == 2
+                const float S = lds_transpose_reduce16<DA>(s_red, lane, v_mx, v_my, v_cx, v_cy, v_cz, v_op, v_r, v_g, v_b, v_dep);
+#elif GGS_BWD_RED == 1
                 const float S = lds_transpose_reduce<DA>(s_red, lane, v_mx, v_my, v_cx, v_cy, v_cz, v_op, v_r, v_g, v_b, v_dep);
 #else
                 const float Q1 = swap16_add(swap32_add(v_mx, v_my), swap32_add(v_cx, v_cy));
@@ -545,7 +551,13 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
             // rows of Q1 = (mx, cx, my, cy), of Q2 = (cz, r, op, g); R5 = b in every row (DA: b, b, depth, depth)
 #if GGS_WHATIF_NORED       // what-if: no cross-lane reduction at all (wrong results: prices the reduction)
             const float S = ((v_mx + v_my) + (v_cx + v_cy)) + ((v_cz + v_op) + (v_r + v_g)) + v_b + v_dep;
-#elif GGS_BWD_RED >= 1
+#elif GGS_WHATIF_SKIPRED   // what-if: GGS_WHATIF_SKIPRED sixteenths of the entries skip reduction + atomic (wrong results): what
+            // 32x16 / 32x32 tiles could save at most through their fewer (tile, splat) entries (0.80 / 0.62 of today's)
+            if ((word & 15u) < GGS_WHATIF_SKIPRED) continue;
+            const float S = lds_transpose_reduce<DA>(s_red, lane, v_mx, v_my, v_cx, v_cy, v_cz, v_op, v_r, v_g, v_b, v_dep);
+#elif GGS_BWD_RED == 2
+            const float S = lds_transpose_reduce16<DA>(s_red, lane, v_mx, v_my, v_cx, v_cy, v_cz, v_op, v_r, v_g, v_b, v_dep);
+#elif GGS_BWD_RED == 1
             const float S = lds_transpose_reduce<DA>(s_red, lane, v_mx, v_my, v_cx, v_cy, v_cz, v_op, v_r, v_g, v_b, v_dep);
 #else
             const float Q1 = swap16_add(swap32_add(v_mx, v_my), swap32_add(v_cx, v_cy));

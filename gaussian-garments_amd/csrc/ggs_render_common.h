@@ -123,6 +123,47 @@ __device__ __forceinline__ float lds_transpose_reduce(float* s_red, int lane, fl
     }
     return s;
 }
+// GGS_BWD_RED = 2: ALL nine / ten values through the plane, no DPP chain for the ninth: lane 4 v + s reads the 16 partials
+// [16 s, 16 s + 16) of value v (4 x ds_read_b128; rows 68 floats apart: conflict-free in the b128 lane groups), 15 adds and
+// two quad DPP adds.  17 VALU instructions (~51 cycles) against 16 (~58 + 6 s_nop), at twice the LDS read volume.
+#define GGS_RED16_STRIDE 68
+template <bool DA>
+__device__ __forceinline__ float lds_transpose_reduce16(float* s_red, int lane, float v0, float v1, float v2, float v3,
+                                                        float v4, float v5, float v6, float v7, float v8, float v9) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f a, b, c, d;
+    const unsigned base = (unsigned)(uintptr_t)s_red;
+    const int slot = min(lane >> 2, DA ? 9 : 8);
+    const unsigned rd = base + (slot * GGS_RED16_STRIDE + (lane & 3) * 16) * 4;
+    asm volatile("s_mov_b32 m0, %9\n\t"
+                 "s_nop 0\n\t"
+                 "ds_write_addtid_b32 %0\n\t"
+                 "ds_write_addtid_b32 %1 offset:272\n\t"
+                 "ds_write_addtid_b32 %2 offset:544\n\t"
+                 "ds_write_addtid_b32 %3 offset:816\n\t"
+                 "ds_write_addtid_b32 %4 offset:1088\n\t"
+                 "ds_write_addtid_b32 %5 offset:1360\n\t"
+                 "ds_write_addtid_b32 %6 offset:1632\n\t"
+                 "ds_write_addtid_b32 %7 offset:1904\n\t"
+                 "ds_write_addtid_b32 %8 offset:2176"
+                 :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8), "s"(base) : "memory", "m0");
+    if (DA) asm volatile("ds_write_addtid_b32 %0 offset:2448" :: "v"(v9) : "memory");
+    asm volatile("ds_read_b128 %0, %4\n\t"
+                 "ds_read_b128 %1, %4 offset:16\n\t"
+                 "ds_read_b128 %2, %4 offset:32\n\t"
+                 "ds_read_b128 %3, %4 offset:48\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(rd) : "memory");
+    float s = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+    s += dpp_fetch<0xB1, 0xf>(s);
+    s += dpp_fetch<0x4E, 0xf>(s);
+    return s;
+}
+template <bool DA>
+__device__ __forceinline__ int lds_reduce16_field(int lane) {
+    return ((lane & 3) == 0 && (lane >> 2) < (DA ? 10 : 9)) ? lane >> 2 : -1;
+}
+
 // GradRec field the lane adds to after lds_transpose_reduce (-1: none)
 template <bool DA>
 __device__ __forceinline__ int lds_reduce_field(int lane) {

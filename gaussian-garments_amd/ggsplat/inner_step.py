@@ -1,8 +1,8 @@
 """Inner optimisation steps of stage 2 (registration) and stage 3 (appearance) -- host-side counterparts
 of s2_registration.py:238-327 and s3_appearance.py:115-147, on the HIP rasterizer and the fused mesh
 binding.  Same order of operations and the same loss composition; what is NOT here (out of scope,
-SURVEY section 2): cloth energies, densify/prune, the StyleUNet (a caller-supplied `net` stands in for it),
-data loading, logging."""
+SURVEY section 2): cloth energies, the StyleUNet (a caller-supplied `net` stands in for it), data loading, logging.
+Density control (s2_registration.py:310-322) is ggsplat.densify; a captured step re-captures itself when it changed P."""
 from __future__ import annotations
 
 from types import SimpleNamespace
@@ -24,15 +24,18 @@ DEFAULT_OPT = SimpleNamespace(                      # arguments/__init__.py:74-1
 DEFAULT_PIPE = SimpleNamespace(convert_SHs_python=False, compute_cov3D_python=False, debug=False)
 
 
-def _photometric(image, gt_image, m, lam, fused: bool):
+def _photometric(image, gt_image, m, lam, fused: bool, tile_count=None):
     """The two image terms of both loops: L1 * (1 - lambda) and 1 - SSIM * lambda.  fused=True: one pair of HIP
     kernels (ggs_photometric_*) in their region-of-interest form -- the image is the output of the render() call just
     made on this thread, and its gradient is only needed on the pixels of tiles that have a splat list; fused=False: the
     reference's PyTorch composition (loss.py), which also masks `image` and `gt_image` in place like the reference does."""
     if fused:
-        tc = R.last_tile_count()
+        # tile_count: the list lengths of the forward that PRODUCED `image` (render()'s pkg["tile_count"]); never the
+        # thread's "most recent forward" looked up here -- another render of the same size in between (an evaluation view)
+        # would hand over lists of the wrong image and silently zero the gradient on tiles that do have splats
+        tc = tile_count
         if tc is not None and tc.shape != (1, ((image.shape[-2] + 15) // 16) * ((image.shape[-1] + 15) // 16)):
-            tc = None                                   # not the forward of this image
+            tc = None
         return fused_photometric_loss(image, gt_image, m, lam, tile_count=tc)
     return l1_loss(image, gt_image, m) * (1.0 - lam), 1.0 - ssim(image, gt_image, m) * lam
 
@@ -46,7 +49,7 @@ def registration_step(gaussians, viewpoint_cam, gt_image, mask, bg, opt=DEFAULT_
     pkg = render(viewpoint_cam, gaussians, pipe, bg)
     image, vsp, vis, radii = pkg["render"], pkg["viewspace_points"], pkg["visibility_filter"], pkg["radii"]
     m = mask if opt.only_foreground_loss else None
-    l_img, l_ssim = _photometric(image, gt_image, m, opt.lambda_dssim, fused_loss)
+    l_img, l_ssim = _photometric(image, gt_image, m, opt.lambda_dssim, fused_loss, pkg.get("tile_count"))
     loss_dict = {"img": l_img, "ssim": l_ssim}
     if first_frame_template:
         # means over the visible Gaussians (s2_registration.py:262-265 index with [visibility_filter]); written with
@@ -93,7 +96,7 @@ def appearance_step(gaussians, net: Callable, viewpoint_cam, gt_image, mask, bg,
     pkg = render(viewpoint_cam, gaussians, pipe, bg, vis_mask=vis_mask)
     image = pkg["render"]
     m = mask if opt.only_foreground_loss else None
-    l_img, l_ssim = _photometric(image, gt_image, m, opt.lambda_dssim, fused_loss)
+    l_img, l_ssim = _photometric(image, gt_image, m, opt.lambda_dssim, fused_loss, pkg.get("tile_count"))
     loss_dict = {"img": l_img, "ssim": l_ssim,
                  "xyz": F.relu(gaussians.local_xyz.norm(dim=1) - opt.threshold_xyz).mean() * opt.lambda_xyz,
                  "scale": F.relu(gaussians.scaling_activation(gaussians._scaling) - opt.threshold_scale

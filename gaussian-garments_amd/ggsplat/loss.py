@@ -1,8 +1,10 @@
-"""Photometric loss of the inner steps -- mirror of utils/loss_utils.py:17-68 (masked L1, 11x11
-Gaussian-window SSIM via grouped conv2d).  Stays PyTorch-ROCm in this round (SURVEY section 8f ranks the
-fused HIP loss kernel as "next" #1).  Like the reference, ssim() multiplies img1 / img2 by the mask
-IN PLACE (loss_utils.py:44-46): callers hand it the rasterizer's output tensor, which is why the
-rasterizer never saves its outputs for backward."""
+"""Photometric loss of the inner steps.  Two forms of the same arithmetic:
+  * l1_loss / ssim: the PyTorch mirror of utils/loss_utils.py:17-68 (masked L1, 11x11 Gaussian-window SSIM via grouped
+    conv2d), reference semantics included: ssim() multiplies img1 / img2 by the mask IN PLACE (loss_utils.py:44-46) --
+    callers hand it the rasterizer's output tensor, which is why the rasterizer never saves its outputs for backward;
+  * fused_photometric_loss: the fused HIP kernels of SURVEY section 8 row f1 (csrc/ggs_loss.hip, ggs_photometric_*): both
+    loss terms and dL/dimage in two row-streaming passes, optionally only where the render backward reads the gradient
+    (tile_count = the region-of-interest form)."""
 from math import exp
 
 import torch

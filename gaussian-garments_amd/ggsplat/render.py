@@ -92,8 +92,12 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
 
     if mask_radii is not None:
         radii = radii * mask_radii.to(radii.dtype)
+    # "tile_count" (not a key of the reference's dict): list lengths of the 16x16 tiles of THIS forward, taken right behind the
+    # rasterizer call so that a later forward on the same thread cannot be mistaken for it; the region-of-interest form of the
+    # fused loss reads it (ggsplat.loss.fused_photometric_loss(..., tile_count=...)).
+    from . import rasterizer as _R
     return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
-            "radii": radii, "3dposition": means3D, "depth": depth, "alpha": alpha}
+            "radii": radii, "3dposition": means3D, "depth": depth, "alpha": alpha, "tile_count": _R.last_tile_count()}
 
 
 def doll_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, override_shs=None,

@@ -79,7 +79,13 @@ typedef struct GgsBinHeader {
 #define GGS_ERR_SIZE (-3)   /* size does not fit the index types                                             */
 
 /* Bytes the caller must provide for the three opaque workspaces.
- * bin_capacity = max number of (Gaussian, tile) instances over all views. */
+ * bin_capacity = max number of (Gaussian, tile) instances over all views.
+ * The workspaces are OPAQUE state for ggs_backward (upstream's geomBuffer / binningBuffer / imgBuffer).  In particular the
+ * image workspace (final_T [V][H][W] f32 | n_contrib [V][H][W] u32) is DEFINED ONLY ON THE PIXELS OF TILES THAT HAVE A SPLAT
+ * LIST: the forward does not store it for empty 16x16 tiles (nothing on the device reads it there; final_T = 1 and
+ * n_contrib = 0 by definition), and a forward that overflowed bin_capacity leaves all of it undefined.  A caller that wants
+ * per-pixel transmittance / contributor counts must patch empty tiles from tile_count (ggs_bin_layout section 1), as
+ * ggsplat.rasterizer.img_sections() does -- or use out_alpha (1 - final_T up to the un-applied terminating splat). */
 int ggs_workspace_sizes(const GgsParams* prm, size_t bin_capacity, size_t* geom_bytes, size_t* img_bytes,
                         size_t* bin_bytes);
 

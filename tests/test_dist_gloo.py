@@ -7,7 +7,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from ggsplat.dist import (all_reduce_bucket, all_reduce_densification_stats, all_reduce_grads, bucket_views,
+from ggsplat.dist import (all_reduce_bucket, all_reduce_densification_stats, all_reduce_grads, all_reduce_parts, bucket_views,
                           flatten_grads, shard_views, unflatten_into)
 
 
@@ -57,7 +57,21 @@ def _worker(rank, world, port, q):
     assert all(v.data_ptr() >= bucket.data_ptr() and v.shape == g.shape for v, g in zip(views, grads))
     acc, den, rad = torch.full((6, 1), float(rank + 1)), torch.ones(6, 1), torch.tensor([1.0 + rank, 5.0 - rank])
     all_reduce_densification_stats(acc, den, rad)
-    q.put((rank, [t.clone() for t in grads], flat.numel(), acc.clone(), den.clone(), rad.clone()))
+    # overlapped exchange (bench.py --overlap): the rank's views in two slices, slice 0 summed over the ranks while slice 1 is
+    # "rendered"; against ONE all-reduce of the rank's whole bucket
+    mine = shard_views(10, rank, world)
+
+    def slice_bucket(vs):
+        out = torch.zeros(sum(torch.Size(s).numel() for s in shapes))
+        for v in vs:
+            g = torch.Generator().manual_seed(100 + v)
+            out += torch.cat([torch.randn(s, generator=g).reshape(-1) for s in shapes])
+        return out
+    half = (len(mine) + 1) // 2
+    over = all_reduce_parts([lambda: slice_bucket(mine[:half]), lambda: slice_bucket(mine[half:])])
+    single = slice_bucket(mine)
+    all_reduce_bucket(single)
+    q.put((rank, [t.clone() for t in grads], flat.numel(), acc.clone(), den.clone(), rad.clone(), over.clone(), single.clone()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -98,8 +112,11 @@ def test_two_rank_gradient_all_reduce_matches_single_process():
         for t in expect:
             t += torch.randn(t.shape, generator=g)
     expect = [t / 10.0 for t in expect]
-    for rank, grads, n, acc, den, rad in res:
+    for rank, grads, n, acc, den, rad, over, single in res:
         assert n == sum(torch.Size(s).numel() for s in shapes)
+        # the overlapped exchange == one all-reduce of the whole bucket, up to the order of the additions
+        assert torch.allclose(over, single, rtol=1e-6, atol=1e-6) and over.shape == single.shape
+        assert torch.allclose(over, torch.cat([t.reshape(-1) for t in expect]) * 10.0, rtol=1e-5, atol=1e-5)
         for a, b in zip(grads, expect):
             assert torch.allclose(a, b, atol=1e-6)
         assert torch.equal(acc, torch.full((6, 1), 3.0)) and torch.equal(den, torch.full((6, 1), 2.0))
@@ -107,3 +124,11 @@ def test_two_rank_gradient_all_reduce_matches_single_process():
     # both ranks end with identical gradients -> identical Adam steps without a parameter broadcast
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
+    assert torch.equal(res[0][6], res[1][6])        # ... through the overlapped exchange too
+
+
+def test_all_reduce_parts_without_a_process_group_is_the_plain_sum():
+    a, b = torch.arange(6.0), torch.ones(6)
+    out = all_reduce_parts([lambda: a, lambda: b])
+    assert torch.equal(out, a + b) and torch.equal(a, torch.arange(6.0))        # inputs untouched
+    assert all_reduce_parts([lambda: a]) is a

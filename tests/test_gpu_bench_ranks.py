@@ -47,6 +47,24 @@ def test_bench_spawns_its_ranks_and_sums_gradients(tmp_path, graph):
     assert rel < 1e-6, rel
 
 
+@pytest.mark.parametrize("graph", [True, False])
+def test_overlapped_gradient_exchange_gives_the_same_bucket(tmp_path, graph):
+    """`--overlap 2`: every rank renders its views in two slices and all-reduces slice 0 while slice 1 renders
+    (ggsplat.dist.all_reduce_parts).  Same bucket as the single all-reduce and as one rank, up to fp32 summation order; the
+    line says how the exchange was done.  Also with ONE rank (two captured slices, no collective)."""
+    extra = [] if graph else ["--no-graph"]
+    one, g1 = _run(["--gpus", "1"] + extra, tmp_path, "one")
+    two, g2 = _run(["--gpus", "2", "--backend", "gloo", "--single-device", "--overlap", "2"] + extra, tmp_path, "two_overlap")
+    solo, g3 = _run(["--gpus", "1", "--overlap", "2"] + extra, tmp_path, "one_overlap")
+    assert two["n_gpus"] == 2 and two["config"]["all_reduce_parts"] == 2 and "overlapped" in two["config"]["collective"]
+    assert one["config"]["all_reduce_parts"] == 1 and one["config"]["collective"].startswith("none")
+    assert solo["config"]["all_reduce_parts"] == 2
+    for g in (g2, g3):
+        assert g.shape == g1.shape
+        rel = float((g1.double() - g.double()).abs().sum() / g1.double().abs().sum())
+        assert rel < 1e-6, rel
+
+
 def test_two_rank_bucket_against_the_oracle_at_config3_size(tmp_path):
     """BASELINE configs[2] at its own size: 100 000 mesh-bound Gaussians, 1920x1080, the inner loop of
     s2_registration.py:238-327 with the views sharded over TWO ranks (views[rank::2], one captured step per rank, one

@@ -57,15 +57,16 @@ class RefState:
         self.percent_dense = m.percent_dense
 
     def bound(self):
-        xyz, scaling, rot = HO.mesh_bind(self.verts, self.faces, self.binding, self.p["_xyz"], self.p["_scaling"],
-                                         self.p["_rotation"])
-        return xyz, scaling, rot
+        # the host oracle is a CPU restatement: bind there, compare on the GPU
+        xyz, scaling, rot = HO.mesh_bind(self.verts.cpu(), self.faces.cpu(), self.binding.cpu(), self.p["_xyz"].cpu(),
+                                         self.p["_scaling"].cpu(), self.p["_rotation"].cpu())
+        return xyz.to(DEV), scaling.to(DEV), rot.to(DEV)
 
     def face_scaling(self):
         Fn = self.faces.shape[0]
-        z = torch.zeros(Fn, 3, device=DEV)
-        ident = torch.tensor([1.0, 0, 0, 0], device=DEV).repeat(Fn, 1)
-        return HO.mesh_bind(self.verts, self.faces, torch.arange(Fn, device=DEV), z, z, ident)[1][:, :1]
+        z = torch.zeros(Fn, 3)
+        ident = torch.tensor([1.0, 0, 0, 0]).repeat(Fn, 1)
+        return HO.mesh_bind(self.verts.cpu(), self.faces.cpu(), torch.arange(Fn), z, z, ident)[1][:, :1].to(DEV)
 
     def prune(self, mask):
         mask = mask.clone()
@@ -220,7 +221,7 @@ def test_captured_step_recaptures_when_density_control_changes_P():
         a, b = getattr(m, n).detach(), getattr(twin, n).detach()
         assert a.shape[0] == P1
         assert float((a - b).abs().sum() / b.abs().sum().clamp_min(1e-12)) < 1e-4, n
-    assert float((m.mesh.v - twin.mesh.v).abs().max()) < 1e-5
+    assert float((m.mesh.v.detach() - twin.mesh.v.detach()).abs().max()) < 1e-5
 
 
 def _attr(name):

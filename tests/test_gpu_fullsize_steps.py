@@ -200,8 +200,8 @@ def test_s3_form_full_size_against_the_oracle_pipeline(skirt):
     assert rel_l1(pkg["render"], co.color) <= REL_L1_TOL
     assert rel_l1(pkg["depth"], co.depth) <= REL_L1_TOL and rel_l1(pkg["alpha"], co.alpha) <= REL_L1_TOL
     for k, r in (("img", l_img), ("ssim", l_ssim), ("xyz", l_xyz), ("scale", l_sc), ("opacity", l_op)):
-        assert abs(float(out[k]) - float(r)) <= 2e-5 * max(1.0, abs(float(r))), k
-    assert float(l_xyz) > 0 and float(l_sc) > 0 and float(l_op) > 0      # every hinge is active
+        assert abs(float(out[k].detach()) - float(r.detach())) <= 2e-5 * max(1.0, abs(float(r.detach()))), k
+    assert float(l_xyz.detach()) > 0 and float(l_sc.detach()) > 0 and float(l_op.detach()) > 0      # every hinge is active
     gpu = [getattr(model, n).grad for n in NAMES] + [model.mesh.v.grad, xo.grad, so.grad]
     _report_and_bound("s3 form, 100k / 1080p", NAMES + ["mesh.v", "net.xyz_off", "net.sh_off"], gpu, leaves, scale, e2e)
     # Gaussians that were masked out receive only the regulariser gradients
