@@ -163,7 +163,24 @@ __global__ __launch_bounds__(1024) void ggs_k_scan_order_one(ScanArgs a, uint32_
     __shared__ uint32_t wsum[16], wemp[16];
     if (tid < GGS_NBUCKET) { s_bucket[tid] = 0; s_cur[tid] = 0; }
     __syncthreads();
+    // The thread's tile counts are loaded ONCE, all loads in flight together (this single workgroup is a latency chain: as two
+    // conditional loops that re-read tile_count it spent most of its 14 us waiting for one dependent global load after the other).
+    constexpr int PER_REG = 16;                      // up to 16384 tiles (4K: 32640 tiles take the generic path)
+    const bool in_regs = per <= PER_REG;
+    uint32_t creg[PER_REG];
+#pragma unroll
+    for (int i = 0; i < PER_REG; ++i) creg[i] = (in_regs && i < per && t0 + i < a.T) ? cnt[t0 + i] : 0u;
     uint32_t local = 0, n_empty = 0;
+    if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < PER_REG; ++i)
+            if (i < per && t0 + i < a.T) {
+                const uint32_t c = creg[i];
+                local += c;
+                if (c == 0) ++n_empty;
+                else atomicAdd(&s_bucket[ggs_len_bucket(c)], 1u);
+            }
+    } else {
     for (int i = 0; i < per; ++i)
         if (t0 + i < a.T) {
             const uint32_t c = cnt[t0 + i];
@@ -171,6 +188,7 @@ __global__ __launch_bounds__(1024) void ggs_k_scan_order_one(ScanArgs a, uint32_
             if (c == 0) ++n_empty;
             else atomicAdd(&s_bucket[ggs_len_bucket(c)], 1u);
         }
+    }
     // inclusive scans (list entries, empty tiles) inside each wave64, then across the 16 waves
     const int lane = tid & 63, wave = tid >> 6;
     uint32_t x = local, e = n_empty;
@@ -200,7 +218,11 @@ __global__ __launch_bounds__(1024) void ggs_k_scan_order_one(ScanArgs a, uint32_
     uint32_t run = wbase + x - local, er = ebase + e - n_empty;
     for (int i = 0; i < per; ++i)
         if (t0 + i < a.T) {
-            const uint32_t c = cnt[t0 + i];
+            uint32_t c = 0;
+            if (in_regs) {
+#pragma unroll
+                for (int k = 0; k < PER_REG; ++k) c = k == i ? creg[k] : c;     // static register indices (no scratch)
+            } else c = cnt[t0 + i];
             off[t0 + i] = run;
             run += c;
             uint32_t pos;

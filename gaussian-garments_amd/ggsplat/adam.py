@@ -62,6 +62,39 @@ class GraphAdam:
         """Steps taken by the most-stepped parameter."""
         return max((int(st["state"][:8].view(torch.int64).item()) for st in self.state.values()), default=0)
 
+    # ---- checkpoints (the reference's capture() / restore() store optimizer.state_dict(), scene/gaussian_model.py:63-90) --
+    def state_dict(self) -> Dict:
+        """torch.optim.Optimizer.state_dict() layout: parameters numbered in group order, per-parameter state {step, exp_avg,
+        exp_avg_sq}, param_groups with "params" = those numbers."""
+        idx, state, groups = 0, {}, []
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                st = self.state[p]
+                state[idx] = {"step": st["state"][:8].view(torch.int64)[0].to(torch.float32).clone(),
+                              "exp_avg": st["exp_avg"].clone(), "exp_avg_sq": st["exp_avg_sq"].clone()}
+                ids.append(idx)
+                idx += 1
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "betas": self.betas, "eps": self.eps, "params": ids})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd: Dict) -> None:
+        flat = [p for g in self.param_groups for p in g["params"]]
+        for i, st in sd["state"].items():
+            p = flat[int(i)]
+            mine = self.state[p]
+            mine["exp_avg"].copy_(st["exp_avg"])
+            mine["exp_avg_sq"].copy_(st["exp_avg_sq"])
+            # the device-side AdamState {i64 step, f32 1 - b1^t, f32 sqrt(1 - b2^t), f64 b1^t, f64 b2^t} (csrc/ggs_adam.hip)
+            n = int(float(st["step"]))
+            b1, b2 = self.betas
+            import struct
+            raw = struct.pack("<qffdd", n, 1.0 - b1 ** n, (1.0 - b2 ** n) ** 0.5, b1 ** n, b2 ** n)
+            mine["state"][:32].copy_(torch.frombuffer(bytearray(raw), dtype=torch.uint8))
+        for g, gs in zip(self.param_groups, sd["param_groups"]):
+            g["lr"] = gs["lr"]
+        self.push_lr()
+
     # ---- torch.optim.Optimizer surface ------------------------------------------------------------------
     def zero_grad(self, set_to_none: bool = True) -> None:
         for g in self.param_groups:

@@ -40,6 +40,55 @@ def _photometric(image, gt_image, m, lam, fused: bool, tile_count=None):
     return l1_loss(image, gt_image, m) * (1.0 - lam), 1.0 - ssim(image, gt_image, m) * lam
 
 
+class _HingeRegularisers(torch.autograd.Function):
+    """The two hinge terms of the first-frame template (s2_registration.py:262-265) as ONE autograd node on the kernels of
+    csrc/ggs_regaux.hip: loss_xyz = lambda_xyz mean_vis relu(|_xyz| - thr), loss_scale = lambda_scale mean_vis |relu(exp(_scaling)
+    - thr)|_2, means over the Gaussians with radii > 0.  The kernels produce values AND gradients in two launches; the PyTorch
+    composition is ~12 forward and ~15 backward nodes, most of the eager step's autograd time.  Used by registration_step when
+    fused_loss=True; tested against the composition (tests/test_gpu_inner_step.py)."""
+
+    @staticmethod
+    def forward(ctx, xyz, log_scaling, radii, thr_xyz, lam_xyz, thr_scale, lam_scale):
+        import ctypes as C
+        from ._lib import check, lib, ptr
+        dev = xyz.device
+        P = xyz.shape[0]
+        x, ls = xyz.detach(), log_scaling.detach()
+        x = x if x.is_contiguous() else x.contiguous()
+        ls = ls if ls.is_contiguous() else ls.contiguous()
+        d_xyz, d_ls = torch.zeros_like(x), torch.zeros_like(ls)
+        out = torch.empty(3, device=dev, dtype=torch.float32)
+        scratch = torch.empty(4, device=dev, dtype=torch.float32)
+        r = radii if (radii.dtype is torch.int32 and radii.is_contiguous()) else radii.to(torch.int32).contiguous()
+        check(lib().ggs_registration_aux(P, ptr(x), ptr(ls), ptr(r), None, None, None, None, float(thr_xyz), float(lam_xyz),
+                                         float(thr_scale), float(lam_scale), ptr(d_xyz), ptr(d_ls), None, None, None, ptr(out),
+                                         ptr(scratch), None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+              "ggs_registration_aux")
+        ctx.saved = (d_xyz, d_ls)
+        ctx.mark_non_differentiable(radii)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, g_xyz, g_scale):
+        d_xyz, d_ls = ctx.saved
+        return (None if g_xyz is None else d_xyz * g_xyz, None if g_scale is None else d_ls * g_scale, None, None, None, None, None)
+
+
+def _densification_stats_fused(gaussians, vsp_grad, radii, hdr):
+    """max_radii2D / xyz_gradient_accum / denom of the visible Gaussians in one launch (ggs_registration_aux, statistics only);
+    hdr: the forward's {num_rendered, overflow} words when a guarded (replayable) step must leave them alone on overflow."""
+    import ctypes as C
+    from ._lib import check, lib, ptr
+    g = gaussians
+    dev = g._xyz.device
+    r = radii if (radii.dtype is torch.int32 and radii.is_contiguous()) else radii.to(torch.int32).contiguous()
+    gr = vsp_grad if vsp_grad.is_contiguous() else vsp_grad.contiguous()
+    check(lib().ggs_registration_aux(g._xyz.shape[0], None, None, ptr(r), ptr(gr), None, None, None, 0.0, 0.0, 0.0, 0.0, None, None,
+                                     ptr(g.max_radii2D), ptr(g.xyz_gradient_accum), ptr(g.denom), None, None,
+                                     None if hdr is None else ptr(hdr[1:2]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+          "ggs_registration_aux")
+
+
 def registration_step(gaussians, viewpoint_cam, gt_image, mask, bg, opt=DEFAULT_OPT, pipe=DEFAULT_PIPE,
                       first_frame_template: bool = True, track_densification: bool = True,
                       optimizer_step: bool = True, fused_loss: bool = False) -> Dict[str, torch.Tensor]:
@@ -51,7 +100,10 @@ def registration_step(gaussians, viewpoint_cam, gt_image, mask, bg, opt=DEFAULT_
     m = mask if opt.only_foreground_loss else None
     l_img, l_ssim = _photometric(image, gt_image, m, opt.lambda_dssim, fused_loss, pkg.get("tile_count"))
     loss_dict = {"img": l_img, "ssim": l_ssim}
-    if first_frame_template:
+    if first_frame_template and fused_loss and gaussians._xyz.is_cuda:
+        loss_dict["xyz"], loss_dict["scale"] = _HingeRegularisers.apply(
+            gaussians._xyz, gaussians._scaling, radii, opt.threshold_xyz, opt.lambda_xyz, opt.threshold_scale, opt.lambda_scale)
+    elif first_frame_template:
         # means over the visible Gaussians (s2_registration.py:262-265 index with [visibility_filter]); written with
         # masks so that nothing depends on a host-side count -- same values, and the step stays graph-capturable
         visf = vis.to(image.dtype)
@@ -64,7 +116,11 @@ def registration_step(gaussians, viewpoint_cam, gt_image, mask, bg, opt=DEFAULT_
     with torch.no_grad():
         graph_opt = isinstance(gaussians.optimizer, GraphAdam)
         hdr = R.last_header() if graph_opt else None            # {num_rendered, overflow} of this step's forward
-        if first_frame_template and track_densification:
+        fused_stats = (fused_loss and gaussians.max_radii2D.dtype is torch.float32 and gaussians.max_radii2D.is_contiguous()
+                       and vsp.grad is not None and vsp.grad.shape[0] == gaussians.max_radii2D.shape[0])
+        if first_frame_template and track_densification and fused_stats:
+            _densification_stats_fused(gaussians, vsp.grad, radii, hdr)
+        elif first_frame_template and track_densification:
             mr = gaussians.max_radii2D
             new_mr = torch.where(vis, torch.max(mr, radii.to(mr.dtype)), mr)
             ok = None

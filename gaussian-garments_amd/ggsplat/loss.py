@@ -45,6 +45,31 @@ def ssim(img1, img2, mask=None, window_size=11, size_average=True):
 # ---------------------------------------------------------------------------------------------------
 # Fused HIP version (libggsplat.so: ggs_photometric_forward / _backward) -- the two loss terms of the inner
 # steps and the gradient w.r.t. the rendered image in two tile passes instead of ~25 PyTorch kernels.
+def _f32c4(t):
+    """Contiguous float32 [V, C, H, W] view of an image tensor; the common case (already that) costs attribute reads only."""
+    t = t.detach()
+    if t.dtype is not torch.float32:
+        t = t.float()
+    if not t.is_contiguous():
+        t = t.contiguous()
+    return t if t.dim() == 4 else t.unsqueeze(0)
+
+
+_scratch_bytes = {}          # (V, H, W) -> bytes of the inter-pass scratch (one C call per shape instead of one per loss)
+_loss_consts = {}            # (device, lambda, n) -> the constant vectors of the value / gradient epilogues
+
+
+def _consts(dev, lam, n):
+    k = (dev.index, lam, n)
+    c = _loss_consts.get(k)
+    if c is None:
+        if len(_loss_consts) > 64:
+            _loss_consts.clear()
+        c = _loss_consts[k] = (torch.tensor([[(1.0 - lam) / n, -lam / n]], device=dev), torch.tensor([[0.0, 1.0]], device=dev),
+                               torch.tensor([[1.0 - lam, -lam]], device=dev))
+    return c
+
+
 class _FusedPhotometric(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, gt, mask, lambda_dssim, tile_count=None):
@@ -52,19 +77,19 @@ class _FusedPhotometric(torch.autograd.Function):
         from ._lib import check, lib, ptr
         if image.device.type != "cuda":
             raise RuntimeError("ggsplat fused loss runs on the GPU only (no CPU path in the product)")
-        img = image.detach().float().contiguous()
-        img = img if img.dim() == 4 else img.unsqueeze(0)
-        g = gt.detach().float().contiguous()
-        g = g if g.dim() == 4 else g.unsqueeze(0)
+        img, g = _f32c4(image), _f32c4(gt)
         V, _, H, W = img.shape
         m = None
         if mask is not None:
-            m = mask.detach().float().contiguous().reshape(-1, 1, H, W)
+            m = _f32c4(mask.reshape(-1, 1, H, W))
             m = m if m.shape[0] == V else m.expand(V, 1, H, W).contiguous()
         L = lib()
         dev = img.device
         sums = torch.empty(V, 2, device=dev, dtype=torch.float32)
-        scratch = torch.empty(L.ggs_photometric_scratch_bytes(V, H, W), device=dev, dtype=torch.uint8)
+        nbytes = _scratch_bytes.get((V, H, W))
+        if nbytes is None:
+            nbytes = _scratch_bytes[(V, H, W)] = int(L.ggs_photometric_scratch_bytes(V, H, W))
+        scratch = torch.empty(nbytes, device=dev, dtype=torch.uint8)
         tc = None
         if tile_count is not None:
             tc = tile_count.contiguous()
@@ -74,20 +99,31 @@ class _FusedPhotometric(torch.autograd.Function):
                                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
               "ggs_photometric_forward")
         lam = float(lambda_dssim)
-        n = 3.0 * H * W
-        ctx.saved = (img.clone() if img.data_ptr() == image.data_ptr() else img, g, m, scratch, lam, image.shape, tc)
-        return sums[:, 0] / n * (1.0 - lam), 1.0 - sums[:, 1] / n * lam
+        scale, bias, _ = _consts(dev, lam, 3.0 * H * W)
+        # The backward re-reads the image.  It is NOT copied (24 MB per 1080p view): like the rasterizer's autograd node this
+        # one records the version counter of the caller's tensor and refuses a backward after an in-place edit -- what
+        # save_for_backward would do, without keeping the producer's graph alive through a saved output.
+        shares = img.data_ptr() == image.data_ptr()
+        ctx.saved = (img, g, m, scratch, lam, image.shape, tc, image if shares else None, image._version if shares else 0)
+        out = torch.addcmul(bias, sums, scale)          # [V, 2]: (sum|x - y| (1 - lambda) / n,  1 - sum ssim lambda / n)
+        return out[:, 0], out[:, 1]
 
     @staticmethod
     def backward(ctx, g_img, g_ssim):
         import ctypes as C
         from ._lib import check, lib, ptr
-        img, g, m, scratch, lam, in_shape, tc = ctx.saved
+        img, g, m, scratch, lam, in_shape, tc, src, ver = ctx.saved
+        if src is not None and src._version != ver:
+            raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
+                               f"the image handed to fused_photometric_loss is at version {src._version}; expected version {ver} "
+                               "(clone it first if it must be edited between the loss and its backward)")
         V, _, H, W = img.shape
         dev = img.device
-        z = torch.zeros(V, device=dev)
-        w = torch.stack([(g_img if g_img is not None else z).reshape(V) * (1.0 - lam),
-                         (g_ssim if g_ssim is not None else z).reshape(V) * (-lam)], dim=1).float().contiguous()
+        _, _, wvec = _consts(dev, lam, 3.0 * H * W)
+        if g_img is None or g_ssim is None:
+            z = torch.zeros(V, device=dev)
+            g_img, g_ssim = (z if g_img is None else g_img), (z if g_ssim is None else g_ssim)
+        w = torch.stack((g_img.reshape(V), g_ssim.reshape(V)), dim=1).float() * wvec
         # region of interest: the kernels leave dL/dimage alone outside the boxes that touch a non-empty tile -- zero there, so
         # that a gradient summed with other consumers of the image stays finite
         dimg = torch.empty_like(img) if tc is None else torch.zeros_like(img)
@@ -100,8 +136,8 @@ class _FusedPhotometric(torch.autograd.Function):
 def fused_photometric_loss(image, gt, mask=None, lambda_dssim: float = 0.2, tile_count=None):
     """(l1_loss(image, gt, mask) * (1 - lambda), 1 - ssim(image, gt, mask) * lambda), per view when the inputs
     are batched [V,3,H,W], through the fused HIP kernels.  Unlike the reference's ssim() it does not mask
-    `image` / `gt` in place (the masking happens inside the kernels); the image is copied for the backward
-    because callers may still mutate the rasterizer's output.
+    `image` / `gt` in place (the masking happens inside the kernels).  The image is NOT copied for the backward: an in-place
+    edit of it between this call and loss.backward() raises autograd's "modified by an inplace operation" error.
     tile_count (rasterizer.last_tile_count() of the forward that rendered `image`): region-of-interest form -- the loss
     VALUES are the same, the gradient w.r.t. the image is computed only where the rasterizer's backward reads it (pixels of
     tiles that have a list) and is zero elsewhere: right for every parameter behind the rasterizer, not a full dL/dimage."""

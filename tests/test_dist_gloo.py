@@ -76,6 +76,9 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+_last_failure = []
+
+
 def _run_two_ranks():
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
@@ -88,9 +91,11 @@ def _run_two_ranks():
         for p in procs:
             p.join(timeout=60)
         if any(p.exitcode != 0 for p in procs):
+            _last_failure.append(f"exit codes {[p.exitcode for p in procs]}")
             return None
         return res
-    except Exception:
+    except Exception as e:
+        _last_failure.append(f"{type(e).__name__}: {e}; exit codes {[p.exitcode for p in procs]}")
         return None
     finally:
         for p in procs:
@@ -100,11 +105,11 @@ def _run_two_ranks():
 
 def test_two_rank_gradient_all_reduce_matches_single_process():
     res = None
-    for _ in range(3):                      # a rendezvous can lose a port race on a busy box: retry with a new port
+    for _ in range(4):                      # a rendezvous can lose a port race on a busy box: retry with a new port
         res = _run_two_ranks()
         if res is not None:
             break
-    assert res is not None, "gloo world-size-2 run failed 3 times"
+    assert res is not None, f"gloo world-size-2 run failed 4 times: {_last_failure}"
     shapes = [(6, 3), (6, 1), (6, 1, 3), (4, 3)]
     expect = [torch.zeros(s) for s in shapes]
     for v in range(10):

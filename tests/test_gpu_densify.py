@@ -24,7 +24,7 @@ def small_model(seed=0, graph_adam=False):
     g = torch.Generator().manual_seed(seed + 5)
     p["_xyz"] = torch.randn(f.shape[0], 3, generator=g) * 0.05
     m = MeshGaussianModel.from_tensors(v, f, p, sh_degree=1, device=DEV)
-    m.training_setup(DEFAULT_OPT, is_ff=True)
+    m.training_setup(DEFAULT_OPT, is_ff=True, optimizer="torch")
     if graph_adam:
         m.optimizer = GraphAdam(m.optimizer.param_groups, eps=1e-15)
     P = m._xyz.shape[0]

@@ -221,7 +221,7 @@ def test_s2_form_full_size_against_the_oracle_pipeline(skirt):
     bg = torch.zeros(3)
     cam = _cam_to(cams[13], "cuda")
     model = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
-    model.training_setup(opt, is_ff=True)
+    model.training_setup(opt, is_ff=True, optimizer="torch")
     out = registration_step(model, cam, gt.cuda(), mask.cuda(), bg.cuda(), opt=opt, optimizer_step=False, fused_loss=True)
     pkg = out["render_pkg"]
 
@@ -281,7 +281,7 @@ def test_graphed_registration_step_full_size(skirt):
     sides = []
     for graph in (False, True):
         m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
-        m.training_setup(opt, is_ff=True)
+        m.training_setup(opt, is_ff=True, optimizer="torch")
         if graph:
             m.optimizer = GraphAdam(m.optimizer.param_groups, lr=0.0, eps=1e-15)
         sides.append(m)

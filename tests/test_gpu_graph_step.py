@@ -71,7 +71,7 @@ def _model(v, f, params, opt, graph: bool):
     from ggsplat.adam import GraphAdam
     from ggsplat.mesh_gaussian_model import MeshGaussianModel
     m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
-    m.training_setup(opt, is_ff=True)
+    m.training_setup(opt, is_ff=True, optimizer="torch")
     if graph:
         m.optimizer = GraphAdam(m.optimizer.param_groups, lr=0.0, eps=1e-15)
     return m
@@ -133,7 +133,7 @@ def test_graphed_mesh_only_step_without_mask(lean):
     models = []
     for graph in (False, True):
         m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
-        m.training_setup(opt, is_ff=False)
+        m.training_setup(opt, is_ff=False, optimizer="torch")
         m.optimizer.param_groups[0]["lr"] = 1e-3
         if graph:
             m.optimizer = GraphAdam(m.optimizer.param_groups, lr=0.0, eps=1e-15)
@@ -307,3 +307,43 @@ def test_graphed_appearance_step_with_a_convolutional_net():
     # the two nets trained in step: the style mapping's first layer after three Adam steps
     wg, we = net_g.net.mapping[0].weight.detach(), net_e.net.mapping[0].weight.detach()
     assert float((wg - we).abs().mean()) <= 5e-4 * float(we.abs().mean()) + 1e-7
+
+
+def test_training_setup_default_is_graph_adam_with_state_dict_round_trip():
+    """training_setup() on the GPU builds a GraphAdam (one launch for all parameter tensors); its state_dict() has torch's
+    layout and load_state_dict() restores moments, step counts and bias corrections: a restored optimiser continues exactly
+    like the original, and like torch.optim.Adam within 2e-6."""
+    from ggsplat.adam import GraphAdam
+    from ggsplat.inner_step import DEFAULT_OPT
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    v, f, params, cams, gts, masks = _scene(seed=3)
+    gen = torch.Generator(device="cuda").manual_seed(5)
+
+    def make(kind):
+        m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
+        m.training_setup(DEFAULT_OPT, is_ff=True, optimizer=kind)
+        return m
+    a, b, t = make("auto"), make("auto"), make("torch")
+    assert isinstance(a.optimizer, GraphAdam) and isinstance(t.optimizer, torch.optim.Adam)
+    assert [g["name"] for g in a.optimizer.param_groups] == [g["name"] for g in t.optimizer.param_groups]
+    grads = [[torch.randn(p.shape, device="cuda", generator=gen) * 1e-2 for p in a.parameters()] for _ in range(5)]
+
+    def run(m, gs):
+        for g in gs:
+            for p, gi in zip(m.parameters(), g):
+                p.grad = gi.clone()
+            m.optimizer.step()
+            m.optimizer.zero_grad()
+    run(a, grads[:3]); run(t, grads)
+    sd = a.optimizer.state_dict()
+    assert set(sd) == {"state", "param_groups"} and len(sd["state"]) == 7 and float(sd["state"][0]["step"]) == 3.0
+    with torch.no_grad():
+        for pb, pa in zip(b.parameters(), a.parameters()):
+            pb.copy_(pa)
+    b.optimizer.load_state_dict(sd)
+    run(a, grads[3:]); run(b, grads[3:])
+    for pa, pb, pt in zip(a.parameters(), b.parameters(), t.parameters()):
+        pa, pb, pt = pa.detach(), pb.detach(), pt.detach()
+        assert torch.equal(pa, pb)
+        if pa.numel():                              # _features_rest is empty at SH degree 0
+            assert float((pa - pt).abs().max()) <= 2e-6 * float(pt.abs().max()) + 1e-9

@@ -52,7 +52,7 @@ def test_registration_step_matches_oracle_pipeline():
     opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "threshold_xyz": 0.3, "threshold_scale": 0.5})
     v, f, params, cams, gt, mask = _scene(sh_degree=0)
     model = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
-    model.training_setup(opt, is_ff=True)
+    model.training_setup(opt, is_ff=True, optimizer="torch")
     bg = torch.tensor([0.0, 0.0, 0.0])
     names = ["_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation"]
     for it, cam_i in enumerate((0, 4)):

@@ -164,7 +164,7 @@ def test_steps_with_the_region_of_interest_loss_give_the_same_gradients():
     grads = []
     for roi in (True, False):
         m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
-        m.training_setup(IS.DEFAULT_OPT, is_ff=True)
+        m.training_setup(IS.DEFAULT_OPT, is_ff=True, optimizer="torch")
         orig = IS.R.last_tile_count
         if not roi:
             IS.R.last_tile_count = lambda: None

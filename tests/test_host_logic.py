@@ -78,7 +78,9 @@ def test_render_mirror_default_path(render_mod):
     pc = _pc()
     out = render_mod.render(cam, pc, pipe, torch.zeros(3))
     rs, kw = _StubRasterizer.calls[-1]
-    assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii", "3dposition", "depth", "alpha"}
+    # the reference's keys (gaussian_renderer/__init__.py:114-122) + "tile_count": the list lengths of THIS forward for the
+    # region-of-interest loss (an extra key a caller of the reference's dict never looks at)
+    assert set(out) == {"render", "viewspace_points", "visibility_filter", "radii", "3dposition", "depth", "alpha", "tile_count"}
     assert rs.image_height == 48 and rs.image_width == 64 and rs.sh_degree == 1 and rs.prefiltered is False
     assert abs(rs.tanfovx - math.tan(cam.FoVx * 0.5)) < 1e-12
     assert kw["shs"] is pc.get_features and kw["colors_precomp"] is None
