@@ -524,7 +524,7 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
                 const bool valid = (pos < nc[q]) & (power <= 0.f) & (ar >= GGS_ALPHA_MIN);
                 // Lanes that did not blend this splat sit out (EXEC mask): their (T, B) and sums keep their values, and a
                 // quadrant nobody blended skips the block on the scalar branch.  (The select form -- alpha = G = 0 in those
-                // lanes -- costs two v_cndmask per quadrant: -2.3 % kernel time, tools/dbg/ab_libs.sh.)
+                // lanes -- costs two v_cndmask per quadrant: -2.3 % kernel time, tools/dbg/job.sh ab.)
                 // Geometry terms are accumulated as RAW moments of h = G dL/dG over the pixels
                 //   (sum h, sum h dx, sum h dy, sum h dx^2, sum h dx dy, sum h dy^2);
                 // the per-splat constants (conic, opacity, -1/2) are applied once per Gaussian in the

@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (must precede the CDLL below: one HIP runtime per process)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# GGS_LIB_PATH: load another build of the same library (A/B timing of kernel variants, tools/dbg/ab_libs.sh)
+# GGS_LIB_PATH: load another build of the same library (A/B timing of kernel variants, tools/dbg/job.sh ab)
 LIB_PATH = os.environ.get("GGS_LIB_PATH") or os.path.normpath(os.path.join(_HERE, "..", "csrc", "libggsplat.so"))
 
 

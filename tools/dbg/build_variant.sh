@@ -1,7 +1,7 @@
 #!/bin/bash
 # build_variant.sh NAME [sed-script-file | -e 'sed expr' ...] : copy csrc to a scratch dir, apply the sed edits to ggs_render.hip
 # (or the file named by VARIANT_FILE), build, and keep the library as csrc/variants/NAME.so (A/B timing via GGS_LIB_PATH,
-# tools/dbg/ab_libs.sh).  What-if builds may compute WRONG results on purpose; they are never the product library.
+# tools/dbg/job.sh ab).  What-if builds may compute WRONG results on purpose; they are never the product library.
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 NAME=$1; shift

@@ -18,6 +18,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/gs -o g -- python 
 python $R/tools/rocpd_summary.py $(find $R/gpurun_out/gs -name "*.db" | head -1) --cycles 60 --anchor k_adam_multi > $R/gpurun_out/prof_${N}_graph_step_kernels.md 2>&1
 grep "graphed s2 step" $R/gpurun_out/gs.log >> $R/gpurun_out/prof_${N}_graph_step_kernels.md
 rm -rf $R/gpurun_out/gs
+( cd $R; echo; echo "Unprofiled (two runs of \`python tools/profile_graph_step.py 256\`):"; python tools/profile_graph_step.py 256 | tail -1; python tools/profile_graph_step.py 256 | tail -1 ) >> $R/gpurun_out/prof_${N}_graph_step_kernels.md 2>/dev/null
 # the default bench line needs the traffic / VALU collections of THIS build in profiles/: copy them in on the box first
 cd $R
 for f in gpurun_out/prof_${N}_*; do cp $f profiles/$(basename $f | sed 's/^prof_//'); done
