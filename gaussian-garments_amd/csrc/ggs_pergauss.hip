@@ -10,6 +10,11 @@
 // that radii / tile rectangles / sort keys are bit-identical to oracle/splat_oracle.c.
 #include "ggs_kernels.h"
 
+// 1: the per-Gaussian backward stages the SH coefficients of its 256 Gaussians in LDS once (A/B switch, see preprocess_bwd_body)
+#ifndef GGS_PREBWD_SH_LDS
+#define GGS_PREBWD_SH_LDS 1
+#endif
+
 namespace {
 
 template <int DEG>
@@ -360,6 +365,24 @@ __device__ __forceinline__ float* ggs_grad_slot(const PreBwdArgs& a, int c, int 
 
 template <int DEG>
 __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a) {
+    constexpr int NK3 = 3 * (DEG + 1) * (DEG + 1);
+#if GGS_PREBWD_SH_LDS
+    // SH coefficients of the workgroup's 256 Gaussians, staged ONCE: the view loop below re-read them from global memory for every
+    // view -- a lane's 12 NK bytes as 16-byte loads whose 64 lanes touch 64 different cache lines each (19 MB per view through
+    // the L2 at K = 16).  Row stride NK3 | 1 floats: lane l reads bank (stride l + j) mod 32, conflict-free.
+    constexpr int SH_LD = NK3 | 1;
+    __shared__ float s_sh[DEG > 0 ? 256 * SH_LD : 1];
+    const bool stage_sh = DEG > 0 && !a.colors && a.dL_dsh;
+    if (stage_sh) {
+        const size_t g0 = (size_t)blockIdx.x * 256;
+        const int n_here = min(256, a.P - (int)g0);
+        for (int i = threadIdx.x; i < n_here * NK3; i += 256) {
+            const int sidx = i / NK3, j = i - sidx * NK3;
+            s_sh[sidx * SH_LD + j] = a.shs[(g0 + sidx) * a.K * 3 + j];
+        }
+        __syncthreads();
+    }
+#endif
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= a.P) return;
     const float m[3] = {a.means3D[3 * (size_t)g], a.means3D[3 * (size_t)g + 1], a.means3D[3 * (size_t)g + 2]};
@@ -387,12 +410,17 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a) {
         const SplatAux ax = a.aux[vg];
         const int radius = ax.radius;
         float* o2 = a.dL_dmeans2D ? a.dL_dmeans2D + 3 * vg : nullptr;
+        // The gradient record and the opacity are requested TOGETHER with the aux word, not behind the branch on it: a lane's
+        // view loop is a chain of dependent global-load latencies (3 waves per SIMD at SH degree 3), and this halves it.  A culled
+        // splat's record is read for nothing (48 B; the record is zero-filled, never unmapped).
+        const float4* gp = reinterpret_cast<const float4*>(a.acc + vg);
+        float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];   // mx my cx cy | cz op r g | b depth - -
+        float opac_early = reinterpret_cast<const float4*>(a.rec + vg)[1].y;
+        asm volatile("" : "+v"(g0.x), "+v"(g1.x), "+v"(g2.x), "+v"(opac_early));      // keep the loads in front of the branch
         if (radius <= 0) {
             if (o2) { o2[0] = 0.f; o2[1] = 0.f; o2[2] = 0.f; }
             continue;
         }
-        const float4* gp = reinterpret_cast<const float4*>(a.acc + vg);
-        const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];   // mx my cx cy | cz op r g | b depth - -
         const float* __restrict__ view = a.view + 16 * v;
         const float* __restrict__ proj = a.proj + 16 * v;
         const float tanfovx = a.tanfov[2 * v], tanfovy = a.tanfov[2 * v + 1];
@@ -409,7 +437,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a) {
         const float det = ca * cc - cb * cb;
         const float d2i = 1.f / (det * det + GGS_DET_EPS);
         // raw pixel moments -> gradients w.r.t. the conic and the pixel mean (constants applied once here)
-        const float opac = reinterpret_cast<const float4*>(a.rec + vg)[1].y;   // SplatRec.opacity
+        const float opac = opac_early;                     // SplatRec.opacity
         const float det_inv = 1.f / det;
         const float kx = cc * det_inv, ky = -cb * det_inv, kz = ca * det_inv;     // the conic
         const float q0 = -0.5f * opac * g0.z, q1 = -opac * g0.w, q2 = -0.5f * opac * g1.x;
@@ -466,7 +494,11 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a) {
             float d[3] = {m[0] - campos[0], m[1] - campos[1], m[2] - campos[2]};
             const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             d[0] = d[0] / len; d[1] = d[1] / len; d[2] = d[2] / len;
+#if GGS_PREBWD_SH_LDS
+            const float* sh = DEG > 0 ? s_sh + threadIdx.x * SH_LD : a.shs + (size_t)g * a.K * 3;   // degree 0: sh is never read
+#else
             const float* sh = a.shs + (size_t)g * a.K * 3;
+#endif
             sh_backward<DEG>(sh, dshr, d, len, gsh, dmean);
         }
     }
