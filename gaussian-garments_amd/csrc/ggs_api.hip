@@ -80,9 +80,9 @@ int check_params(const GgsParams* p) {
         return fail(GGS_ERR_ARG, "bad sizes P=%d W=%d H=%d n_views=%d", p->P, p->W, p->H, p->n_views);
     if (p->n_views > 65535) return fail(GGS_ERR_SIZE, "n_views=%d exceeds the grid.y limit 65535", p->n_views);
     if ((size_t)p->P * (size_t)p->n_views > (size_t)1 << 40) return fail(GGS_ERR_SIZE, "P*n_views too large");
-    if (p->P >= (1 << GGS_ID_BITS)) return fail(GGS_ERR_SIZE, "P=%d exceeds the 2^28 id space of the tile lists", p->P);
+    if (p->P >= (1 << GGS_ID_BITS)) return fail(GGS_ERR_SIZE, "P=%d exceeds the 2^%d id space of the tile lists", p->P, (int)GGS_ID_BITS);
     if (p->W > 32767 || p->H > 32767) return fail(GGS_ERR_SIZE, "image %dx%d exceeds the 16-bit pixel boxes of the records", p->W, p->H);
-    const size_t tiles = (size_t)((p->W + GGS_TILE - 1) / GGS_TILE) * (size_t)((p->H + GGS_TILE - 1) / GGS_TILE);
+    const size_t tiles = (size_t)((p->W + GGS_TILE_W - 1) / GGS_TILE_W) * (size_t)((p->H + GGS_TILE - 1) / GGS_TILE);
     if (tiles * (size_t)p->n_views >= ((size_t)1 << 31))
         return fail(GGS_ERR_SIZE, "n_views * tiles = %zu work items exceed the launch grid", tiles * (size_t)p->n_views);
     return GGS_OK;
@@ -117,7 +117,7 @@ int bwd_splits(const GgsParams* p) {
 }
 
 // launches with fewer (view, tile) work items than this use the one-wave-per-quadrant render kernels
-#define GGS_QUAD_ITEMS_DEFAULT 57344       // measured crossover at config 2: ~7 views of 8160 tiles (tools/dbg/quad_threshold.py)
+#define GGS_QUAD_ITEMS_DEFAULT (57344 / GGS_TS)       // measured crossover at config 2: ~7 views of 8160 tiles (tools/dbg/quad_threshold.py)
 // (tuning knob: the environment variable GGS_QUAD_ITEMS overrides the threshold; read once)
 static int quad_items() {
     static const int v = [] {
@@ -131,7 +131,7 @@ static int quad_items() {
 struct Dims { int gx, gy, T; };
 Dims dims(const GgsParams* p) {
     Dims d;
-    d.gx = (p->W + GGS_TILE - 1) / GGS_TILE;
+    d.gx = (p->W + GGS_TILE_W - 1) / GGS_TILE_W;
     d.gy = (p->H + GGS_TILE - 1) / GGS_TILE;
     d.T = d.gx * d.gy;
     return d;
@@ -147,6 +147,11 @@ const char* ggs_version(void) { return "ggsplat 0.2 gfx950"; }
 #define GGS_SRC_HASH "unknown"
 #endif
 const char* ggs_build_id(void) { return GGS_SRC_HASH; }
+int ggs_tile_size(int* width, int* height) {
+    if (width) *width = GGS_TILE_W;
+    if (height) *height = GGS_TILE;
+    return GGS_OK;
+}
 
 int ggs_profile_enable(int on) { g_prof.on = on != 0; return GGS_OK; }
 
@@ -321,7 +326,7 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
     if (!(phases & PHASE_RENDER)) { prof_collect(s); return GGS_OK; }
     if (p->P > 0) {
         ScatterArgs a;
-        a.P = p->P; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.rec = (const SplatRec*)geom; a.header = header;
+        a.P = p->P; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.gx16 = (p->W + 15) / 16; a.rec = (const SplatRec*)geom; a.header = header;
         a.aux = (const SplatAux*)((const char*)geom + ggs_align((size_t)V * p->P * sizeof(SplatRec)));
         a.tile_cursor = tile_cursor; a.tile_offset = tile_offset; a.view_base = view_base; a.keys = keys;
         prof_start(K_SCATTER, s);
@@ -354,7 +359,7 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
         a.rec = (const SplatRec*)geom; a.bg = bg; a.out_color = out_color; a.out_depth = out_depth;
         a.out_alpha = out_alpha; a.final_T = final_T; a.n_contrib = n_contrib;
         prof_start(K_RENDER_FWD, s);
-        if (n_items < GGS_QUAD_ITEMS) hipLaunchKernelGGL(ggs_k_render_fwd_quad, dim3((unsigned)n_items * 4), dim3(64), 0, s, a);
+        if (n_items < GGS_QUAD_ITEMS) hipLaunchKernelGGL(ggs_k_render_fwd_quad, dim3((unsigned)n_items * GGS_NQ), dim3(64), 0, s, a);
         else hipLaunchKernelGGL(ggs_k_render_fwd, dim3((unsigned)n_items), dim3(64), 0, s, a);
         prof_stop(K_RENDER_FWD, s);
         GGS_TRY(check("render_fwd", s, p->debug));
@@ -427,7 +432,7 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
         prof_start(K_RENDER_BWD, s);
         const bool da = dL_ddepth || dL_dalpha;
         if (a.n_items < GGS_QUAD_ITEMS) {
-            const dim3 gridQ((unsigned)(a.n_items * 4));
+            const dim3 gridQ((unsigned)(a.n_items * GGS_NQ));
             if (da) hipLaunchKernelGGL(ggs_k_render_bwd_da_quad, gridQ, dim3(64), 0, s, a);
             else hipLaunchKernelGGL(ggs_k_render_bwd_quad, gridQ, dim3(64), 0, s, a);
         } else if (da) hipLaunchKernelGGL(ggs_k_render_bwd_da, gridT, dim3(64), 0, s, a);

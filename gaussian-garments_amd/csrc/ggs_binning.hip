@@ -244,11 +244,11 @@ __global__ __launch_bounds__(1024) void ggs_k_scan_order_one(ScanArgs a, uint32_
 
 namespace {
 
-// sort order = (depth bits, Gaussian id): the key is depth << 32 | id << 4 | quadrant mask, so the plain 64-bit
-// comparison already is that order.  The id word handed to the render kernels is mask << 28 | id = the low
-// key word rotated right by 4.
+// sort order = (depth bits, Gaussian id): the key is depth << 32 | id << GGS_NQ | sub-block mask, so the plain 64-bit
+// comparison already is that order.  The id word handed to the render kernels is mask << GGS_ID_BITS | id = the low
+// key word rotated right by GGS_NQ.
 __device__ __forceinline__ uint32_t key_to_id_word(unsigned long long k) {
-    return __builtin_amdgcn_alignbit((uint32_t)k, (uint32_t)k, 4);
+    return __builtin_amdgcn_alignbit((uint32_t)k, (uint32_t)k, GGS_NQ);
 }
 
 template <typename KeyPtr>

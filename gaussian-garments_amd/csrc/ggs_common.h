@@ -19,14 +19,24 @@
 
 #include "../../include/ggsplat.h"
 
-#define GGS_TILE 16
+#define GGS_TILE 16              // tile HEIGHT, and the reference's tile size (the rect rule of A.1 step 6 is in 16-pixel units)
+// Tile WIDTH: 16 (the product) or 32 (A/B build `make HIPFLAGS+=-DGGS_TILE_W=32`: 8 pixels per lane, 0.80 x the (tile, splat)
+// entries -- VERDICT r3 #1a; measured in profiles/r04_bwd_variants.md).  A tile is GGS_QX x 2 sub-blocks of 8x8 pixels
+// ("quadrants"): sub-block q covers x in [8 (q % GGS_QX), +8), y in [8 (q / GGS_QX), +8); one wave64 owns a tile, lane l owns pixel
+// (l & 7, l >> 3) of every sub-block.
+#ifndef GGS_TILE_W
+#define GGS_TILE_W 16
+#endif
+#define GGS_TS (GGS_TILE_W / 16)     // reference 16-pixel columns per tile
+#define GGS_QX (GGS_TILE_W / 8)
+#define GGS_NQ (2 * GGS_QX)
 #define GGS_BLOCK 256            // threads per render block = one 16x16 tile = 4 wave64
 #define GGS_BATCH 256            // splats staged in LDS per round
 #define GGS_SORT_CAP 4096        // per-tile list length sorted in LDS (above: global fallback)
-// id word of the per-tile lists: bits 0..27 Gaussian id, bits 28..31 quadrant mask (bit q set: the
-// splat can reach / was blended in 8x8 quadrant q of the tile).  Limits P to 2^28.
-#define GGS_ID_BITS 28
-#define GGS_ID_MASK 0x0fffffffu
+// id word of the per-tile lists: low GGS_ID_BITS bits Gaussian id, the GGS_NQ bits above it the sub-block mask (bit q set: the
+// splat can reach / was blended in sub-block q of the tile).  Limits P to 2^28 (2^24 with 32-pixel tiles).
+#define GGS_ID_BITS (32 - GGS_NQ)
+#define GGS_ID_MASK ((1u << GGS_ID_BITS) - 1u)
 #define GGS_NBUCKET 16            // list-length classes used to order the per-tile work items
 #define GGS_BUCKET_COUNT_OFF 64   // byte offsets inside the header region
 #define GGS_BUCKET_CURSOR_OFF 128
@@ -149,7 +159,8 @@ __device__ __forceinline__ NonEmptyItems ggs_nonempty_items(const uint32_t* buck
     return it;
 }
 
-// Tile rectangle of a splat (A.1 step 6); must be bit-identical wherever it is recomputed.
+// Tile rectangle of a splat (A.1 step 6) in the REFERENCE's 16x16 tiles (gx = ceil(W / 16) columns); must be bit-identical
+// wherever it is recomputed.
 __device__ __forceinline__ void ggs_tile_rect(float px, float py, float r, int gx, int gy, int& x0, int& y0,
                                               int& x1, int& y1) {
     int a0 = (int)((px - r) / (float)GGS_TILE), b0 = (int)((py - r) / (float)GGS_TILE);
@@ -232,30 +243,43 @@ __device__ __forceinline__ bool ggs_box_reachable(const Footprint& f, float x0, 
     return inside ? f.lim > 0.f : ggs_min(qv, qh) <= f.lim;
 }
 
-// Which 8x8 quadrants of tile (tx, ty) the splat can be blended in, positioned at bits 28..31 of the id word;
+// Which 8x8 sub-blocks of tile (tx, ty) the splat can be blended in, positioned at the top GGS_NQ bits of the id word;
 // 0 = the tile can be dropped from the splat's list (output-invariant).  The AABB pre-test is integer work.
+// c0, c1: the splat's (culled) reference rectangle in 16-pixel columns [c0, c1): with tiles wider than 16 pixels the
+// reference still cuts the splat at ITS tile columns, so sub-blocks outside them must stay clear.
 __device__ __forceinline__ unsigned long long ggs_quad_mask(const Footprint& f, unsigned bbx, unsigned bby, int tx,
-                                                            int ty) {
+                                                            int ty, int c0, int c1) {
     const int xmin = ggs_bb_min(bbx), xmax = ggs_bb_max(bbx), ymin = ggs_bb_min(bby), ymax = ggs_bb_max(bby);
-    const int ox = tx * GGS_TILE, oy = ty * GGS_TILE;
-    const bool hx0 = xmin <= ox + 7 && xmax >= ox, hx1 = xmin <= ox + 15 && xmax >= ox + 8;
-    const bool hy0 = ymin <= oy + 7 && ymax >= oy, hy1 = ymin <= oy + 15 && ymax >= oy + 8;
+    const int ox = tx * GGS_TILE_W, oy = ty * GGS_TILE;
     const float fx = (float)ox, fy = (float)oy;
-    unsigned m = 0;
-    if (hx0 && hy0 && ggs_box_reachable(f, fx, fy, fx + 7.f, fy + 7.f)) m |= 1u;
-    if (hx1 && hy0 && ggs_box_reachable(f, fx + 8.f, fy, fx + 15.f, fy + 7.f)) m |= 2u;
-    if (hx0 && hy1 && ggs_box_reachable(f, fx, fy + 8.f, fx + 7.f, fy + 15.f)) m |= 4u;
-    if (hx1 && hy1 && ggs_box_reachable(f, fx + 8.f, fy + 8.f, fx + 15.f, fy + 15.f)) m |= 8u;
+    unsigned m = 0, aabb = 0;
+#pragma unroll
+    for (int q = 0; q < GGS_NQ; ++q) {
+        const int bx = ox + 8 * (q % GGS_QX), by = oy + 8 * (q / GGS_QX);
+        const bool col = GGS_TS == 1 || ((bx >> 4) >= c0 && (bx >> 4) < c1);
+        const bool hit = col && xmin <= bx + 7 && xmax >= bx && ymin <= by + 7 && ymax >= by;
+        if (hit) aabb |= 1u << q;
+        if (hit && ggs_box_reachable(f, (float)bx, (float)by, (float)bx + 7.f, (float)by + 7.f)) m |= 1u << q;
+    }
+    (void)fx; (void)fy;
     // The LIST MEMBERSHIP of the tile is decided by ggs_tile_reachable alone (used identically by the histogram
-    // and the scatter).  If rounding makes all four quadrant tests fail on a tile that passed, keep the AABB mask.
-    if (!m) m = (hx0 && hy0 ? 1u : 0u) | (hx1 && hy0 ? 2u : 0u) | (hx0 && hy1 ? 4u : 0u) | (hx1 && hy1 ? 8u : 0u);
+    // and the scatter).  If rounding makes all sub-block tests fail on a tile that passed, keep the AABB mask.
+    if (!m) m = aabb;
     return (unsigned long long)m << GGS_ID_BITS;
 }
 
-// Can the splat be blended anywhere in tile (tx, ty)?  (the tile is already inside the culled rectangle)
-__device__ __forceinline__ bool ggs_tile_reachable(const Footprint& f, int tx, int ty) {
-    const float fx = (float)(tx * GGS_TILE), fy = (float)(ty * GGS_TILE);
-    return ggs_box_reachable(f, fx, fy, fx + 15.f, fy + 15.f);
+// Can the splat be blended anywhere in tile (tx, ty)?  (the tile is already inside the culled rectangle; c0, c1 as above:
+// only the tile's 16-pixel columns inside [c0, c1) count)
+__device__ __forceinline__ bool ggs_tile_reachable(const Footprint& f, int tx, int ty, int c0, int c1) {
+    int bx0 = tx * GGS_TILE_W, bx1 = bx0 + GGS_TILE_W - 1;
+    if (GGS_TS > 1) { bx0 = bx0 > c0 * 16 ? bx0 : c0 * 16; bx1 = bx1 < c1 * 16 - 1 ? bx1 : c1 * 16 - 1; }
+    const float fy = (float)(ty * GGS_TILE);
+    return ggs_box_reachable(f, (float)bx0, fy, (float)bx1, fy + 15.f);
+}
+
+// [x0, x1) in the reference's 16-pixel columns -> tile columns [X0, X1)
+__device__ __forceinline__ void ggs_tile_columns(int x0, int x1, int& X0, int& X1) {
+    X0 = x0 / GGS_TS; X1 = (x1 + GGS_TS - 1) / GGS_TS;
 }
 
 // Rotation matrix (row-major) of a (w,x,y,z) quaternion, no normalisation (A.0).

@@ -36,7 +36,7 @@ struct OrderArgs {
 };
 
 struct ScatterArgs {
-    int P, gx, gy, T;
+    int P, gx, gy, T, gx16;
     const SplatRec* rec;
     const SplatAux* aux;
     const GgsBinHeader* header;

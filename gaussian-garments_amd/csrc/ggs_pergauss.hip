@@ -86,6 +86,7 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
     const size_t vg = (size_t)v * a.P + g;
     SplatRec* rec = a.rec + vg;
     const int gx = a.gx, gy = a.gy;
+    const int gx16 = (a.W + 15) / 16;           // the reference's 16-pixel tile columns (== gx unless tiles are wider)
 
     int radius = 0;
     SplatRec out;
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
             float rad = ceilf(3.f * sqrtf(ggs_max(l1, l2)));
             float px = ((ndx + 1.0f) * (float)a.W - 1.0f) * 0.5f;
             float py = ((ndy + 1.0f) * (float)a.H - 1.0f) * 0.5f;
-            ggs_tile_rect(px, py, rad, gx, gy, x0, y0, x1, y1);
+            ggs_tile_rect(px, py, rad, gx16, gy, x0, y0, x1, y1);
             if ((x1 - x0) * (y1 - y0) != 0) {
                 radius = (int)rad;
                 out.px = px; out.py = py;
@@ -170,6 +171,9 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
         ggs_cull_rect(out.bbx, out.bby, x0, y0, x1, y1);
         has = x0 < x1 && y0 < y1;
     }
+    const int c0 = x0, c1 = x1;                 // reference columns the splat may be blended in
+    ggs_tile_columns(c0, c1, x0, x1);           // from here on x0, x1 are TILE columns
+    (void)gx;
     const Footprint fp = ggs_footprint(out.px, out.py, out.cx, out.cy, out.cz, out.opacity);
     uint32_t* cnt = a.tile_count + (size_t)v * a.T;
     const TileWindow w = block_tile_window(s_box, has, x0, y0, x1, y1);
@@ -184,7 +188,7 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
         if (has)
             for (int y = y0; y < y1; ++y)
                 for (int x = x0; x < x1; ++x, ++idx)
-                    if (ggs_tile_reachable(fp, x, y)) {
+                    if (ggs_tile_reachable(fp, x, y, c0, c1)) {
                         atomicAdd(&s_cnt[(y - w.y0) * w.w + (x - w.x0)], 1u);
                         if (idx < GGS_TILE_BITS_MAX) bits |= 1ull << idx;
                     }
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
     } else if (has) {
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x, ++idx)
-                if (ggs_tile_reachable(fp, x, y)) {
+                if (ggs_tile_reachable(fp, x, y, c0, c1)) {
                     atomicAdd(&cnt[y * gx + x], 1u);
                     if (idx < GGS_TILE_BITS_MAX) bits |= 1ull << idx;
                 }
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
 }
 
 // K3: grid (ceil(P/256), V).  For every (splat, tile) instance take a slot in the tile's
-// segment and write the 64-bit key  depth bits << 32 | id << 4 | quadrant mask  -- the mask sits BELOW the id so
+// segment and write the 64-bit key  depth bits << 32 | id << GGS_NQ | sub-block mask  -- the mask sits BELOW the id so
 // that plain 64-bit comparisons order by (depth, id) without masking anything out (an id occurs once per tile).
 // Slot order is arbitrary; the per-tile sort makes the final order deterministic.
 __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
@@ -229,22 +233,24 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
             const SplatRec* rec = a.rec + (size_t)v * a.P + g;
             const float4 r0 = reinterpret_cast<const float4*>(rec)[0];
             const float4 r2 = reinterpret_cast<const float4*>(rec)[2];
-            ggs_tile_rect(r0.x, r0.y, (float)radius, a.gx, a.gy, x0, y0, x1, y1);
+            ggs_tile_rect(r0.x, r0.y, (float)radius, a.gx16, a.gy, x0, y0, x1, y1);
             const float4 r1 = reinterpret_cast<const float4*>(rec)[1];
             bbx = __float_as_uint(r2.z); bby = __float_as_uint(r2.w);
             fp = ggs_footprint(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
             ggs_cull_rect(bbx, bby, x0, y0, x1, y1);
-            key = ((unsigned long long)__float_as_uint(r2.y) << 32) | ((unsigned)g << 4);   // low nibble: quadrant mask
+            key = ((unsigned long long)__float_as_uint(r2.y) << 32) | ((unsigned)g << GGS_NQ);   // low bits: sub-block mask
             has = x0 < x1 && y0 < y1;
         }
     }
+    const int c0 = x0, c1 = x1;                 // reference columns; x0, x1 become tile columns
+    ggs_tile_columns(c0, c1, x0, x1);
     uint32_t* cur = a.tile_cursor + (size_t)v * a.T;
     const uint32_t* off = a.tile_offset + (size_t)v * a.T;
     unsigned long long* keys = a.keys + a.view_base[v];
     const TileWindow w = block_tile_window(s_box, has, x0, y0, x1, y1);
     // membership of tile (x, y) = bit of the mask the preprocess pass stored (rects of <= 64 tiles), else re-tested
     const bool small = (x1 - x0) * (y1 - y0) <= GGS_TILE_BITS_MAX;
-    auto member = [&](unsigned idx, int x, int y) { return small ? ((bits >> idx) & 1ull) != 0 : ggs_tile_reachable(fp, x, y); };
+    auto member = [&](unsigned idx, int x, int y) { return small ? ((bits >> idx) & 1ull) != 0 : ggs_tile_reachable(fp, x, y, c0, c1); };
     unsigned idx = 0;
     if (w.dense) {
         // count in LDS -> one returning global atomic per touched tile claims the workgroup's run of
@@ -271,7 +277,7 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
             for (int y = y0; y < y1; ++y)
                 for (int x = x0; x < x1; ++x, ++idx) {
                     if (!member(idx, x, y)) continue;
-                    const unsigned long long qm = ggs_quad_mask(fp, bbx, bby, x, y);
+                    const unsigned long long qm = ggs_quad_mask(fp, bbx, bby, x, y, c0, c1);
                     const int i = (y - w.y0) * w.w + (x - w.x0);
                     keys[(size_t)s_base[i] + atomicAdd(&s_cnt[i], 1u)] = key | (qm >> GGS_ID_BITS);
                 }
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x, ++idx) {
                 if (!member(idx, x, y)) continue;
-                const unsigned long long qm = ggs_quad_mask(fp, bbx, bby, x, y);
+                const unsigned long long qm = ggs_quad_mask(fp, bbx, bby, x, y, c0, c1);
                 const int t = y * a.gx + x;
                 const uint32_t slot = atomicAdd(&cur[t], 1u);
                 keys[(size_t)off[t] + slot] = key | (qm >> GGS_ID_BITS);

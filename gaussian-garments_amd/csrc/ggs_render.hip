@@ -52,17 +52,20 @@ namespace {
 // (forward 27-29 -> 25 us per view at config 2, 109 -> 100 at config 5).  Returns false when the tile must take the
 // general path (image edge, row pitch not a multiple of 16 bytes).
 __device__ __forceinline__ bool store_empty_tile(const RenderArgs& a, int v, int ox, int oy, int lane) {
-    if ((a.W & 3) != 0 || ox + GGS_TILE > a.W || oy + GGS_TILE > a.H) return false;
+    if ((a.W & 3) != 0 || ox + GGS_TILE_W > a.W || oy + GGS_TILE > a.H) return false;
     const size_t HW = (size_t)a.H * a.W;
-    const size_t pix = (size_t)(oy + (lane >> 2)) * a.W + ox + (lane & 3) * 4;
     const float* bg = a.bg + 3 * v;
-    float* oc = a.out_color + (size_t)v * 3 * HW + pix;
     const float b0 = bg[0], b1 = bg[1], b2 = bg[2];
-    *reinterpret_cast<float4*>(oc) = make_float4(b0, b0, b0, b0);
-    *reinterpret_cast<float4*>(oc + HW) = make_float4(b1, b1, b1, b1);
-    *reinterpret_cast<float4*>(oc + 2 * HW) = make_float4(b2, b2, b2, b2);
-    *reinterpret_cast<float4*>(a.out_depth + (size_t)v * HW + pix) = make_float4(0.f, 0.f, 0.f, 0.f);
-    *reinterpret_cast<float4*>(a.out_alpha + (size_t)v * HW + pix) = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int h = 0; h < GGS_TS; ++h) {           // 16 rows x 64 contiguous bytes per 16-pixel column block of the tile
+        const size_t pix = (size_t)(oy + (lane >> 2)) * a.W + ox + 16 * h + (lane & 3) * 4;
+        float* oc = a.out_color + (size_t)v * 3 * HW + pix;
+        *reinterpret_cast<float4*>(oc) = make_float4(b0, b0, b0, b0);
+        *reinterpret_cast<float4*>(oc + HW) = make_float4(b1, b1, b1, b1);
+        *reinterpret_cast<float4*>(oc + 2 * HW) = make_float4(b2, b2, b2, b2);
+        *reinterpret_cast<float4*>(a.out_depth + (size_t)v * HW + pix) = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4*>(a.out_alpha + (size_t)v * HW + pix) = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     return true;
 }
 
@@ -72,7 +75,7 @@ __device__ __forceinline__ bool store_empty_tile(const RenderArgs& a, int v, int
 // longest tile -- is render_fwd_quadwave below; the backward keeps both mappings in one template.)
 // Same arithmetic per pixel, bit-identical results.
 __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
-    constexpr int NQ = 4, q0 = 0;
+    constexpr int NQ = GGS_NQ, q0 = 0;
     // A forward that overflowed its binning capacity (only possible with a static capacity inside a captured graph) has no
     // lists: every tile is composited as EMPTY, so the outputs are deterministic (background, zero depth / alpha)
     // instead of uninitialised memory.  The overflow word tells the caller to re-run.
@@ -80,7 +83,7 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
     const uint32_t item = a.order[blockIdx.x];   // work items, longest lists first
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
     const int tx = t % a.gx, ty = t / a.gx;
-    const int ox = tx * GGS_TILE, oy = ty * GGS_TILE;
+    const int ox = tx * GGS_TILE_W, oy = ty * GGS_TILE;
     const int px0 = ox + (lane & 7), py0 = oy + (lane >> 3);
     const int L = overflow ? 0 : (int)a.tile_count[(size_t)v * a.T + t];
     const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
@@ -94,7 +97,7 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
     bool inside[NQ];
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-        const int px = px0 + ((q0 + q) & 1) * 8, py = py0 + ((q0 + q) >> 1) * 8;
+        const int px = px0 + ((q0 + q) % GGS_QX) * 8, py = py0 + ((q0 + q) / GGS_QX) * 8;
         inside[q] = px < a.W && py < a.H;
         // a finished pixel parks its x coordinate at +inf: the falloff exponent becomes -inf or NaN and
         // every later splat fails the (power <= 0, alpha >= 1/255) test without a separate flag
@@ -177,7 +180,7 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         if (!inside[q]) continue;
-        const size_t pix = (size_t)(py0 + ((q0 + q) >> 1) * 8) * a.W + (px0 + ((q0 + q) & 1) * 8);
+        const size_t pix = (size_t)(py0 + ((q0 + q) / GGS_QX) * 8) * a.W + (px0 + ((q0 + q) % GGS_QX) * 8);
         a.final_T[(size_t)v * HW + pix] = T[q];
         a.n_contrib[(size_t)v * HW + pix] = last[q];
         oc[pix] = fmaf(T[q], bg0, C0[q]);
@@ -195,19 +198,19 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
 // front) and blended one after the other; the arithmetic per pixel is the same as in render_fwd_body.
 __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
     const bool overflow = a.header->overflow != 0;      // see render_fwd_body: overflowed forward = all tiles empty
-    const uint32_t item = a.order[blockIdx.x >> 2];
-    const int q0 = (int)(blockIdx.x & 3);
+    const uint32_t item = a.order[blockIdx.x / GGS_NQ];
+    const int q0 = (int)(blockIdx.x % GGS_NQ);
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
     const int tx = t % a.gx, ty = t / a.gx;
-    const int px = tx * GGS_TILE + (lane & 7) + (q0 & 1) * 8, py = ty * GGS_TILE + (lane >> 3) + (q0 >> 1) * 8;
+    const int px = tx * GGS_TILE_W + (lane & 7) + (q0 % GGS_QX) * 8, py = ty * GGS_TILE + (lane >> 3) + (q0 / GGS_QX) * 8;
     const int L = overflow ? 0 : (int)a.tile_count[(size_t)v * a.T + t];
     const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
     uint32_t* ids = a.ids + base;
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
     const float inf_v = __builtin_inff();
     if (L == 0) {                 // empty tile: the wave of quadrant 0 stores the whole tile, the other three have nothing to do
-        if ((a.W & 3) == 0 && tx * GGS_TILE + GGS_TILE <= a.W && ty * GGS_TILE + GGS_TILE <= a.H) {
-            if (q0 == 0) store_empty_tile(a, v, tx * GGS_TILE, ty * GGS_TILE, lane);
+        if ((a.W & 3) == 0 && tx * GGS_TILE_W + GGS_TILE_W <= a.W && ty * GGS_TILE + GGS_TILE <= a.H) {
+            if (q0 == 0) store_empty_tile(a, v, tx * GGS_TILE_W, ty * GGS_TILE, lane);
             return;
         }
     }
@@ -322,15 +325,15 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
     // tiles of a view have nothing to differentiate, and their waves -- which used to be interleaved with the real ones for
     // the forward's sake -- exit on one scalar compare behind all the work instead of in front of it.
     const NonEmptyItems it = ggs_nonempty_items(a.bucket_count, (uint32_t)a.n_items);
-    const uint32_t rank = NQ == 4 ? blockIdx.x : blockIdx.x >> 2;
+    const uint32_t rank = NQ == GGS_NQ ? blockIdx.x : blockIdx.x / GGS_NQ;
     if (rank >= it.n) return;
     const uint32_t item = a.order[(size_t)rank * it.stride];
-    const int q0 = NQ == 4 ? 0 : (int)(blockIdx.x & 3);                      // NQ = 1: one wave per quadrant
+    const int q0 = NQ == GGS_NQ ? 0 : (int)(blockIdx.x % GGS_NQ);            // NQ = 1: one wave per sub-block
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
     const int L = (int)a.tile_count[(size_t)v * a.T + t];
     if (L == 0) return;
     const int tx = t % a.gx, ty = t / a.gx;
-    const int ox = tx * GGS_TILE, oy = ty * GGS_TILE;
+    const int ox = tx * GGS_TILE_W, oy = ty * GGS_TILE;
     const int px0 = ox + (lane & 7), py0 = oy + (lane >> 3);
     const size_t HW = (size_t)a.H * a.W;
     const size_t base = (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
@@ -354,7 +357,7 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
         my_bits |= 1u << (GGS_ID_BITS + q0 + q);
-        const int px = px0 + ((q0 + q) & 1) * 8, py = py0 + ((q0 + q) >> 1) * 8;
+        const int px = px0 + ((q0 + q) % GGS_QX) * 8, py = py0 + ((q0 + q) / GGS_QX) * 8;
         const bool inside = px < a.W && py < a.H;
         const size_t pix = (size_t)py * a.W + px;
         pxf[q] = (float)px; pyf[q] = (float)py;
@@ -582,8 +585,8 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
 
 // K5: grid V*T work items (x4 for the per-quadrant variant), block 64.  Separate entry points so the common case
 // (no loss on depth / alpha: s2_registration.py:258-267, s3_appearance.py:131-140) carries no dead work.
-__global__ __launch_bounds__(64) void ggs_k_render_bwd(RenderBwdArgs a) { render_bwd_body<false, 4>(a); }
-__global__ __launch_bounds__(64) void ggs_k_render_bwd_da(RenderBwdArgs a) { render_bwd_body<true, 4>(a); }
+__global__ __launch_bounds__(64) void ggs_k_render_bwd(RenderBwdArgs a) { render_bwd_body<false, GGS_NQ>(a); }
+__global__ __launch_bounds__(64) void ggs_k_render_bwd_da(RenderBwdArgs a) { render_bwd_body<true, GGS_NQ>(a); }
 __global__ __launch_bounds__(64) void ggs_k_render_bwd_quad(RenderBwdArgs a) { render_bwd_body<false, 1>(a); }
 __global__ __launch_bounds__(64) void ggs_k_render_bwd_da_quad(RenderBwdArgs a) { render_bwd_body<true, 1>(a); }
 
@@ -597,15 +600,15 @@ __global__ __launch_bounds__(64) void ggs_k_count_blends(RenderBwdArgs a, unsign
     const int L = (int)a.tile_count[(size_t)v * a.T + t];
     if (L == 0) return;
     const int tx = t % a.gx, ty = t / a.gx;
-    const int px0 = tx * GGS_TILE + (lane & 7), py0 = ty * GGS_TILE + (lane >> 3);
+    const int px0 = tx * GGS_TILE_W + (lane & 7), py0 = ty * GGS_TILE + (lane >> 3);
     const size_t HW = (size_t)a.H * a.W;
     const uint32_t* __restrict__ ids = a.ids + (size_t)a.view_base[v] + a.tile_offset[(size_t)v * a.T + t];
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
-    float pxf[4], pyf[4];
-    int nc[4], maxc = 0;
+    float pxf[GGS_NQ], pyf[GGS_NQ];
+    int nc[GGS_NQ], maxc = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int px = px0 + (q & 1) * 8, py = py0 + (q >> 1) * 8;
+    for (int q = 0; q < GGS_NQ; ++q) {
+        const int px = px0 + (q % GGS_QX) * 8, py = py0 + (q / GGS_QX) * 8;
         pxf[q] = (float)px; pyf[q] = (float)py;
         nc[q] = px < a.W && py < a.H ? (int)a.n_contrib[(size_t)v * HW + (size_t)py * a.W + px] : 0;
         maxc = max(maxc, nc[q]);
@@ -624,7 +627,7 @@ __global__ __launch_bounds__(64) void ggs_k_count_blends(RenderBwdArgs a, unsign
             const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, j);
             const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
+            for (int q = 0; q < GGS_NQ; ++q) {
                 if (!(word & (1u << (GGS_ID_BITS + q)))) continue;
                 const float dx = ra.x - pxf[q], dy = ra.y - pyf[q];
                 const float power = fmaf(ra.z * dx, dx, fmaf(rb.x * dy, dy, (ra.w * dx) * dy));

@@ -69,6 +69,7 @@ _SIGS = {
     "ggs_last_error": (C.c_char_p, []),
     "ggs_version": (C.c_char_p, []),
     "ggs_build_id": (C.c_char_p, []),
+    "ggs_tile_size": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }
 EXPORTS = tuple(_SIGS)
 
@@ -123,6 +124,24 @@ def source_hash() -> str:
 
 def build_id() -> str:
     return lib().ggs_build_id().decode()
+
+
+_tile = None
+
+
+def tile_size():
+    """(width, height) in pixels of the tiles the loaded library bins into: (16, 16) in the product."""
+    global _tile
+    if _tile is None:
+        w, h = C.c_int(), C.c_int()
+        lib().ggs_tile_size(C.byref(w), C.byref(h))
+        _tile = (w.value, h.value)
+    return _tile
+
+
+def n_tiles(W: int, H: int) -> int:
+    tw, th = tile_size()
+    return ((W + tw - 1) // tw) * ((H + th - 1) // th)
 
 
 def dtype_code(dt) -> int:

@@ -40,7 +40,7 @@ def last_tile_count() -> Optional[torch.Tensor]:
     that forward's binning buffer (which it keeps alive).  The region-of-interest form of the fused loss takes it
     (loss.fused_photometric_loss(..., tile_count=...)): dL/dimage is only needed where a tile has a list."""
     b = getattr(_pinned, "last_bin", None)
-    if b is None:
+    if b is None or _lib.tile_size() != (16, 16):          # the region-of-interest loss is cut for 16 x 16 tiles
         return None
     binb, V, T, off = b
     return binb[off:off + V * T * 4].view(torch.int32).reshape(V, T)
@@ -234,7 +234,7 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
     if not capturing:
         _cap_hint[key] = max(cap if n * 2 <= cap else int(n * 2), 1 << 16)
     _last_header = _pinned.last_header = binb[:16].view(torch.int64)
-    _pinned.last_bin = (binb, V, ((W + 15) // 16) * ((H + 15) // 16), _tile_count_offset(L, prm, cap))
+    _pinned.last_bin = (binb, V, _lib.n_tiles(W, H), _tile_count_offset(L, prm, cap))
     if capturing:
         _capture_headers.append(_last_header)
     st = None
@@ -293,7 +293,7 @@ def bin_sections(st: ForwardState) -> Dict[str, torch.Tensor]:
     off = (C.c_size_t * 8)()
     check(lib().ggs_bin_layout(C.byref(st.prm), st.cap, off), "ggs_bin_layout")
     V = st.prm.n_views
-    T = ((st.prm.W + 15) // 16) * ((st.prm.H + 15) // 16)
+    T = _lib.n_tiles(st.prm.W, st.prm.H)
     b = st.bin
 
     def sec(i, nbytes, dt):
@@ -315,9 +315,10 @@ def img_sections(st: ForwardState) -> Dict[str, torch.Tensor]:
     off = (n + 255) & ~255
     final_T = st.img[:n].view(torch.float32).reshape(V, H, W).clone()
     n_contrib = st.img[off:off + n].view(torch.int32).reshape(V, H, W).clone()
-    gx, gy = (W + 15) // 16, (H + 15) // 16
+    tw, th = _lib.tile_size()
+    gx, gy = (W + tw - 1) // tw, (H + th - 1) // th
     empty = (bin_sections(st)["tile_count"].reshape(V, gy, gx) == 0)
-    empty = empty.repeat_interleave(16, 1).repeat_interleave(16, 2)[:, :H, :W]
+    empty = empty.repeat_interleave(th, 1).repeat_interleave(tw, 2)[:, :H, :W]
     final_T[empty] = 1.0
     n_contrib[empty] = 0
     return dict(final_T=final_T, n_contrib=n_contrib)

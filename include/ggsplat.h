@@ -330,6 +330,10 @@ const char* ggs_version(void);
 /* First 16 hex digits of the sha256 over the library's sources (csrc Makefile order): identifies the build a profile or a
  * counter collection belongs to.  No reference counterpart (the upstream extension carries no build id). */
 const char* ggs_build_id(void);
+/* Pixel size of the tiles this build bins into (16 x 16 in the product; a 32 x 16 A/B build exists): the tile grid of
+ * tile_count / ggs_bin_layout is ceil(W / width) x ceil(H / height).  Upstream's BLOCK_X / BLOCK_Y (compile-time constants
+ * of the CUDA extension, no call). */
+int ggs_tile_size(int* width, int* height);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ cp $SRC/*.hip $SRC/*.h $SRC/Makefile $TMP/gaussian-garments_amd/csrc/
 cp $ROOT/include/*.h $TMP/include/
 F=${VARIANT_FILE:-ggs_render.hip}
 if [ $# -gt 0 ]; then sed -i "$@" $TMP/gaussian-garments_amd/csrc/$F; fi
-make -C $TMP/gaussian-garments_amd/csrc -j8 RENDER_EXTRA="$RENDER_EXTRA" PERGAUSS_EXTRA="$PERGAUSS_EXTRA" > $TMP/build.log 2>&1 || { tail -30 $TMP/build.log; exit 1; }
+make -C $TMP/gaussian-garments_amd/csrc -j8 RENDER_EXTRA="$RENDER_EXTRA" PERGAUSS_EXTRA="$PERGAUSS_EXTRA" ALL_EXTRA="$ALL_EXTRA" > $TMP/build.log 2>&1 || { tail -30 $TMP/build.log; exit 1; }
 mkdir -p $SRC/variants
 cp $TMP/gaussian-garments_amd/csrc/libggsplat.so $SRC/variants/$NAME.so
 diff <(cat $SRC/$F) $TMP/gaussian-garments_amd/csrc/$F | head -40 || true
