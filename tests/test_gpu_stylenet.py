@@ -112,6 +112,23 @@ def _record_preactivation_signs(monkeypatch_target, store):
     monkeypatch_target.setattr(SN, "bias_act", spy)
 
 
+def _count_flips(pre):
+    """(units, units whose pre-activation sign differs between the two paths, largest |pre-activation| among those relative
+    to its layer's r.m.s.)"""
+    units = flips = 0
+    worst_rel = 0.0
+    for a, b in zip(pre["hip"], pre["native"]):
+        assert a.shape == b.shape
+        units += a.numel()
+        d = (a > 0) != (b > 0)
+        n = int(d.sum())
+        flips += n
+        if n:
+            rms = float(b.double().pow(2).mean().sqrt())
+            worst_rel = max(worst_rel, float(torch.maximum(a.abs(), b.abs())[d].max()) / rms)
+    return units, flips, worst_rel
+
+
 def test_fp32_gradient_gap_is_explained_by_slope_flips(monkeypatch):
     """The fp32 bars of this file (5e-3 for the small net, 1e-2 at texture 512) are 50-100 x looser than the path's 1e-4, and
     the stated reason is discrete: a leaky-ReLU unit whose pre-activation is within rounding of zero takes the other slope in
@@ -129,39 +146,38 @@ def test_fp32_gradient_gap_is_explained_by_slope_flips(monkeypatch):
     oh, gh = _fwd_bwd(hip, cond, style, w)
     on, gn = _fwd_bwd(nat, cond, style, w)
     assert len(pre["hip"]) == len(pre["native"]) >= 10
-    units = flips = 0
-    worst_rel = 0.0
-    for a, b in zip(pre["hip"], pre["native"]):
-        assert a.shape == b.shape
-        units += a.numel()
-        d = (a > 0) != (b > 0)
-        n = int(d.sum())
-        flips += n
-        if n:
-            rms = float(b.double().pow(2).mean().sqrt())
-            worst_rel = max(worst_rel, float(torch.maximum(a.abs(), b.abs())[d].max()) / rms)
+    units, flips, worst_rel = _count_flips(pre)
     frac = flips / units
     worst = max(_rel(gh[n], gn[n]) for n in gn)
     print(f"\n[slope flips] {flips} of {units} leaky-ReLU units ({frac:.2e}) take different slopes in the two paths; the largest "
           f"|pre-activation| among them is {worst_rel:.1e} of its layer's r.m.s.; worst parameter-gradient difference {worst:.1e}, "
           f"texture {_rel(oh, on):.1e}")
-    assert units > 500_000 and frac <= 1e-4              # a handful of units ...
+    assert units > 400_000 and frac <= 1e-4              # a handful of units ...
     assert flips == 0 or worst_rel <= 1e-4               # ... each within rounding of zero
     assert worst <= (5e-3 if flips else 1e-4)            # no flip -> the path's own bar; with flips the discrete bar
 
 
-def test_reference_channel_table_texture_512():
+def test_reference_channel_table_texture_512(monkeypatch):
     """Texture size 512 (the reference's default, s3_appearance.py:61), 4 -> 51 channels ((3 + 1)^2 * 3 + 3, avatar_net.py:21),
-    style_dim 512, channel table of styleunet.py:662-672: forward + backward on the HIP ops against the native paths, timed."""
+    style_dim 512, channel table of styleunet.py:662-672: forward + backward on the HIP ops against the native paths, timed.
+    The fp32 gradient bar is 1e-4 (the path's own) unless leaky-ReLU units take different slopes in the two paths; then it is
+    1e-2, the flipped units are counted, and each must sit within rounding of zero."""
     hip, nat = _pair(512, 51, 512)
     g = torch.Generator().manual_seed(7)
     cond, style = torch.randn(1, 4, 512, 512, generator=g).cuda(), torch.randn(1, 512, generator=g).cuda()
     w = torch.randn(1, 51, 512, 512, generator=g).cuda()
-    oh, gh = _fwd_bwd(hip, cond, style, w)
-    on, gn = _fwd_bwd(nat, cond, style, w)
+    pre = {}
+    with monkeypatch.context() as mp:
+        _record_preactivation_signs(mp, pre)
+        oh, gh = _fwd_bwd(hip, cond, style, w)
+        on, gn = _fwd_bwd(nat, cond, style, w)
     assert oh.shape == (1, 51, 512, 512) and _rel(oh, on) <= 1e-4
+    units, flips, worst_rel = _count_flips(pre)
     worst = max(_rel(gh[n], gn[n]) for n in gn)
-    assert worst <= 1e-2, worst                     # fp32, 512^2 pixels: summation order of the conv library + slope flips (see above)
+    print(f"\n[StyleUNetLite 512] {flips} of {units} leaky-ReLU units take different slopes in the two paths (largest |pre-activation| "
+          f"{worst_rel:.1e} of the layer r.m.s.); worst parameter-gradient difference {worst:.1e}")
+    assert flips <= 1e-5 * units and (flips == 0 or worst_rel <= 1e-4)
+    assert worst <= (1e-2 if flips else 1e-4), worst
     times = {}
     for name, net in (("hip", hip), ("native", nat)):
         torch.cuda.synchronize()
