@@ -160,8 +160,8 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
                         const int n_stop = (int)__popcll(m_stop);
                         rem[q] -= n_stop; remaining -= n_stop;
                         if (rem[q] == 0) live &= ~(1u << (GGS_ID_BITS + q0 + q));
+                        pxf[q] = sel(m_stop, inf_v, pxf[q]);  // park the finished pixels (only when there are any)
                     }
-                    pxf[q] = sel(m_stop, inf_v, pxf[q]);
                     const float w = sel_or_zero(m_app, wa);
                     C0[q] = fmaf(cr, w, C0[q]);
                     C1[q] = fmaf(cg, w, C1[q]);
@@ -273,8 +273,11 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
                     const float test_T = T - wa;
                     stopA = okA & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
                     const uint64_t app = okA & ~stopA;
-                    remaining -= (int)__popcll(stopA);
-                    pxf = sel(stopA, inf_v, pxf);
+                    if (stopA != 0) {                          // rare: a pixel finishes at most once
+                        asm volatile("" ::: "memory");
+                        remaining -= (int)__popcll(stopA);
+                        pxf = sel(stopA, inf_v, pxf);
+                    }
                     const float w = sel_or_zero(app, wa);
                     C0 = fmaf(a1.z, w, C0); C1 = fmaf(a1.w, w, C1); C2 = fmaf(a2.x, w, C2); D = fmaf(a2.y, w, D);
                     A += w; T -= w;
@@ -291,8 +294,11 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
                     const float test_T = T - wa;
                     const uint64_t stop = okB & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
                     const uint64_t app = okB & ~stop;
-                    remaining -= (int)__popcll(stop);
-                    pxf = sel(stop, inf_v, pxf);
+                    if (stop != 0) {
+                        asm volatile("" ::: "memory");
+                        remaining -= (int)__popcll(stop);
+                        pxf = sel(stop, inf_v, pxf);
+                    }
                     const float w = sel_or_zero(app, wa);
                     C0 = fmaf(b1.z, w, C0); C1 = fmaf(b1.w, w, C1); C2 = fmaf(b2.x, w, C2); D = fmaf(b2.y, w, D);
                     A += w; T -= w;
