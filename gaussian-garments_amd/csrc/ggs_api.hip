@@ -384,6 +384,16 @@ extern "C" {
 int ggs_forward(GGS_FWD_PARAMS) { return forward_impl(PHASE_COUNT | PHASE_RENDER, GGS_FWD_ARGS); }
 int ggs_forward_count(GGS_FWD_PARAMS) { return forward_impl(PHASE_COUNT, GGS_FWD_ARGS); }
 int ggs_forward_render(GGS_FWD_PARAMS) { return forward_impl(PHASE_RENDER, GGS_FWD_ARGS); }
+int ggs_forward_spec(GGS_FWD_PARAMS, void* host_header, void* header_event) {
+    if (!host_header || !header_event) return fail(GGS_ERR_ARG, "ggs_forward_spec: NULL host_header / header_event");
+    GGS_TRY(forward_impl(PHASE_COUNT, GGS_FWD_ARGS));
+    hipStream_t s = (hipStream_t)stream_;
+    // the header is the first 16 bytes of the binning buffer (ggs_bin_layout section 0)
+    if (hipMemcpyAsync(host_header, bin, 16, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipEventRecord((hipEvent_t)header_event, s) != hipSuccess)
+        return fail(GGS_ERR_HIP, "ggs_forward_spec: header copy / event record failed: %s", hipGetErrorString(hipGetLastError()));
+    return forward_impl(PHASE_RENDER, GGS_FWD_ARGS);
+}
 
 int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, const float* shs,
                  const float* colors_precomp, const float* scales, const float* rotations,

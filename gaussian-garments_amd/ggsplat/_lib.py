@@ -37,6 +37,7 @@ _SIGS = {
     "ggs_forward": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 6),
     "ggs_forward_count": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 6),
     "ggs_forward_render": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 6),
+    "ggs_forward_spec": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 8),
     "ggs_backward": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 13 + [C.c_size_t] + [_PTR] * 13 + [C.c_int, _PTR]),
     "ggs_mesh_bind_forward": (C.c_int, [C.c_int, C.c_int] + [_PTR] * 11),
     "ggs_mesh_bind_backward": (C.c_int, [C.c_int, C.c_int] + [_PTR] * 15),

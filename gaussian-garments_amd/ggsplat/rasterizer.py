@@ -72,6 +72,7 @@ def _f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 _ws_sizes: Dict[Tuple, Tuple[int, int, int]] = {}
+_bwd_scratch: Dict[Tuple, int] = {}          # (P, K, V) -> ggs_backward_scratch_bytes (one C call per shape, not per backward)
 _tc_off: Dict[Tuple, int] = {}
 
 
@@ -123,6 +124,7 @@ def _header_event(dev) -> "torch.cuda.Event":
     e = d.get(dev.index)
     if e is None:
         e = d[dev.index] = torch.cuda.Event()
+        e.record(torch.cuda.current_stream(dev))       # torch creates the HIP event lazily: the C side needs the handle
     return e
 
 
@@ -221,11 +223,8 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
         # render, and in the rare overflow case it composites nothing and the call is repeated with the exact size.  The
         # ONLY host sync of the call waits for the header copy (~10 us of GPU work in front of it -- the same point where
         # the upstream extension syncs to size its binning buffer) while the GPU is already compositing.
-        check(L.ggs_forward_count(*args), "ggs_forward_count")
-        host.copy_(binb[:16].view(torch.int64), non_blocking=True)
         ev = _header_event(dev)
-        ev.record(cur_stream)
-        check(L.ggs_forward_render(*args), "ggs_forward_render")
+        check(L.ggs_forward_spec(*args, host.data_ptr(), ev.cuda_event), "ggs_forward_spec")   # count | header copy + event | render
         ev.synchronize()
         n, overflow = int(host[0]), int(host[1])
         if not overflow:
@@ -272,7 +271,13 @@ def backward_views(st: ForwardState, dL_dcolor, dL_ddepth=None, dL_dalpha=None, 
         accumulate = False
     if want_means2D and "means2D" not in g:
         g["means2D"] = new(V, P, 3)
-    scratch = torch.empty(L.ggs_backward_scratch_bytes(C.byref(prm)), device=dev, dtype=torch.uint8)
+    k = (P, K, V)
+    nbytes = _bwd_scratch.get(k)
+    if nbytes is None:
+        if len(_bwd_scratch) > 256:
+            _bwd_scratch.clear()
+        nbytes = _bwd_scratch[k] = int(L.ggs_backward_scratch_bytes(C.byref(prm)))
+    scratch = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     check(L.ggs_backward(C.byref(prm), ptr(st.bg), ptr(st.means3D), ptr(st.shs), ptr(st.colors), ptr(st.scales),
                          ptr(st.rots), ptr(st.cov), ptr(st.view), ptr(st.proj), ptr(st.campos), ptr(st.tanfov),
                          ptr(st.geom), ptr(st.bin), st.cap, ptr(st.img), ptr(dL_dcolor), ptr(dL_ddepth),

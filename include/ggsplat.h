@@ -125,6 +125,20 @@ int ggs_forward_count(const GgsParams* prm, const float* bg, const float* means3
                       const float* rotations, const float* cov3D_precomp, const float* view, const float* proj,
                       const float* campos, const float* tanfov, void* geom, void* bin, size_t bin_capacity,
                       void* img, float* out_color, float* out_depth, float* out_alpha, int* radii, void* stream);
+/*
+ * The eager caller's form of the two phases in ONE call: count phase, then an asynchronous copy of the 16-byte header
+ * {num_rendered, overflow} to `host_header` (pinned host memory) and `hipEventRecord(header_event, stream)`, then the render
+ * phase queued right behind WITHOUT waiting (every kernel of it is guarded by the overflow word on the device).  The caller waits
+ * for the event only (the GPU is already compositing), reads the two words, and repeats the call with a larger buffer in the rare
+ * overflow case.  Same results as ggs_forward; same argument list plus the two handles.  (The upstream extension synchronises at
+ * the same point to size its binning buffer through the resize callback.)
+ */
+int ggs_forward_spec(const GgsParams* prm, const float* bg, const float* means3D, const float* shs,
+                     const float* colors_precomp, const float* opacities, const float* scales,
+                     const float* rotations, const float* cov3D_precomp, const float* view, const float* proj,
+                     const float* campos, const float* tanfov, void* geom, void* bin, size_t bin_capacity,
+                     void* img, float* out_color, float* out_depth, float* out_alpha, int* radii, void* stream,
+                     void* host_header, void* header_event);
 int ggs_forward_render(const GgsParams* prm, const float* bg, const float* means3D, const float* shs,
                        const float* colors_precomp, const float* opacities, const float* scales,
                        const float* rotations, const float* cov3D_precomp, const float* view, const float* proj,

@@ -61,4 +61,4 @@ print(f"{which}: {len(cams) / best:.0f} per second ({best / len(cams) * 1e6:.0f}
 t0 = time.perf_counter(); fn(); t1 = time.perf_counter(); torch.cuda.synchronize()
 print(f"{which}: host issue time {(t1 - t0) / len(cams) * 1e6:.0f} us per iteration (includes the rasterizer's header wait)")
 pr = cProfile.Profile(); pr.enable(); fn(); fn(); torch.cuda.synchronize(); pr.disable()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(rows)
+st = pstats.Stats(pr); st.sort_stats(os.environ.get("SORT", "tottime")).print_stats(rows)
