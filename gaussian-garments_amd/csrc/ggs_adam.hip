@@ -12,33 +12,17 @@
 
 namespace {
 
-struct AdamState { long long step; float bias1; float bias2_sqrt; double pow1; double pow2; };   // 32 bytes, device
-
 struct TickMulti { int n; AdamState* s[16]; };
-
-__device__ __forceinline__ void adam_tick_one(AdamState* s, double beta1, double beta2);
 
 __global__ void k_adam_tick(AdamState* s, double beta1, double beta2, const unsigned long long* guard) {
     if (guard && *guard) return;
-    adam_tick_one(s, beta1, beta2);
+    ggs_adam_tick_one(s, beta1, beta2);
 }
 // one thread per tensor: torch keeps a step count PER PARAMETER (a parameter without gradient skips the step and its
 // bias corrections lag behind), so every tensor has its own state
 __global__ void k_adam_tick_multi(TickMulti m, double beta1, double beta2, const unsigned long long* guard) {
     if (guard && *guard) return;
-    if ((int)threadIdx.x < m.n) adam_tick_one(m.s[threadIdx.x], beta1, beta2);
-}
-
-__device__ __forceinline__ void adam_tick_one(AdamState* s, double beta1, double beta2) {
-    const long long t = s->step + 1;
-    s->step = t;
-    // beta^t as a running double product (torch evaluates beta ** step in Python floats each step; the products agree to
-    // ~t * 2^-53, far below the fp32 the corrections are used in) -- a device-side pow() made this one-thread kernel
-    // the slowest launch of a graph-replayed iteration after the rasterizer and the loss
-    const double p1 = t == 1 ? beta1 : s->pow1 * beta1, p2 = t == 1 ? beta2 : s->pow2 * beta2;
-    s->pow1 = p1; s->pow2 = p2;
-    s->bias1 = (float)(1.0 - p1);
-    s->bias2_sqrt = (float)sqrt(1.0 - p2);
+    if ((int)threadIdx.x < m.n) ggs_adam_tick_one(m.s[threadIdx.x], beta1, beta2);
 }
 
 struct AdamArgs {
@@ -92,18 +76,35 @@ struct AdamMulti {
     float* p[GGS_ADAM_MAX_TENSORS]; const float* g[GGS_ADAM_MAX_TENSORS];
     float* m[GGS_ADAM_MAX_TENSORS]; float* v[GGS_ADAM_MAX_TENSORS];
     const float* lr[GGS_ADAM_MAX_TENSORS];
-    const AdamState* s[GGS_ADAM_MAX_TENSORS]; const unsigned long long* guard;
+    AdamState* s[GGS_ADAM_MAX_TENSORS]; const unsigned long long* guard;
     float beta1, beta2, omb1, omb2, eps;
+    double beta1d, beta2d;
 };
 
-__global__ __launch_bounds__(256) void k_adam_multi(AdamMulti mt) {
+// TICK: the launch also advances the step count / bias corrections of every tensor (what k_adam_tick_multi does in a launch
+// of its own -- ~5 us of a graph-replayed iteration for one wave of work).  Every workgroup derives the corrections of step + 1
+// from the stored state (read-only while any workgroup of the tensor may still read it); the LAST workgroup of a tensor to
+// finish -- a ticket counter in the state -- stores the advanced state and resets the ticket.
+template <bool TICK>
+__device__ __forceinline__ void adam_multi_body(const AdamMulti& mt) {
     if (mt.guard && *mt.guard) return;
     int t = 0;
     while (t + 1 < mt.n && blockIdx.x >= mt.first_block[t + 1]) ++t;
     AdamArgs a;
     a.n = mt.numel[t]; a.p = mt.p[t]; a.g = mt.g[t]; a.m = mt.m[t]; a.v = mt.v[t];
     a.beta1 = mt.beta1; a.beta2 = mt.beta2; a.omb1 = mt.omb1; a.omb2 = mt.omb2; a.eps = mt.eps;
-    const float step_size = *mt.lr[t] / mt.s[t]->bias1, bs = mt.s[t]->bias2_sqrt;
+    AdamState* st = mt.s[t];
+    float bias1 = st->bias1, bs = st->bias2_sqrt;
+    long long tt = 0;
+    double p1 = 0.0, p2 = 0.0;
+    if (TICK) {                                                          // adam_tick_one, without the stores
+        tt = st->step + 1;
+        p1 = tt == 1 ? mt.beta1d : st->pow1 * mt.beta1d;
+        p2 = tt == 1 ? mt.beta2d : st->pow2 * mt.beta2d;
+        bias1 = (float)(1.0 - p1);
+        bs = (float)sqrt(1.0 - p2);
+    }
+    const float step_size = *mt.lr[t] / bias1;
     const unsigned b0 = mt.first_block[t], nb = mt.first_block[t + 1] - b0;
     const size_t n4 = a.n / 4, stride = (size_t)nb * 256;
     float4* p4 = reinterpret_cast<float4*>(a.p);
@@ -123,7 +124,18 @@ __global__ __launch_bounds__(256) void k_adam_multi(AdamMulti mt) {
         const size_t i = n4 * 4 + threadIdx.x;
         adam1(a.p[i], a.g[i], a.m[i], a.v[i], a, step_size, bs);
     }
+    if (TICK) __syncthreads();               // every wave of this workgroup has read the state (its values fed the loop above)
+    if (TICK && threadIdx.x == 0) {
+        // No fence: a workgroup's reads of the state completed before its stores were formed; the new state is read by later
+        // launches only.  (A __threadfence() here is an L2 write-back per workgroup on this part: 9 -> 64 us for the launch.)
+        if (atomicAdd(&st->ticket, 1u) == nb - 1) {                      // every other workgroup of the tensor has read it
+            st->step = tt; st->pow1 = p1; st->pow2 = p2; st->bias1 = bias1; st->bias2_sqrt = bs;
+            atomicExch(&st->ticket, 0u);
+        }
+    }
 }
+__global__ __launch_bounds__(256) void k_adam_multi(AdamMulti mt) { adam_multi_body<false>(mt); }
+__global__ __launch_bounds__(256) void k_adam_tick_multi_step(AdamMulti mt) { adam_multi_body<true>(mt); }
 
 }  // namespace
 
@@ -180,26 +192,26 @@ int ggs_adam_tick_multi(int n_states, void* const* states, double beta1, double 
     return GGS_OK;
 }
 
-int ggs_adam_step_multi(int n_tensors, const size_t* numel, float* const* params, const float* const* grads,
-                        float* const* exp_avgs, float* const* exp_avg_sqs, const float* const* lrs,
-                        const void* const* states, double beta1, double beta2, double eps, const void* guard,
-                        void* stream) {
+static int adam_step_multi(bool tick, const char* who, int n_tensors, const size_t* numel, float* const* params,
+                           const float* const* grads, float* const* exp_avgs, float* const* exp_avg_sqs,
+                           const float* const* lrs, void* const* states, double beta1, double beta2, double eps,
+                           const void* guard, void* stream) {
     ggs_clear_error_();
     if (n_tensors <= 0) return GGS_OK;
-    if (n_tensors > GGS_ADAM_MAX_TENSORS) return ggs_fail_(GGS_ERR_SIZE, "ggs_adam_step_multi: at most %d tensors per call", GGS_ADAM_MAX_TENSORS);
+    if (n_tensors > GGS_ADAM_MAX_TENSORS) return ggs_fail_(GGS_ERR_SIZE, "%s: at most %d tensors per call", who, GGS_ADAM_MAX_TENSORS);
     if (!numel || !params || !grads || !exp_avgs || !exp_avg_sqs || !lrs || !states)
-        return ggs_fail_(GGS_ERR_ARG, "ggs_adam_step_multi: NULL pointer argument");
+        return ggs_fail_(GGS_ERR_ARG, "%s: NULL pointer argument", who);
     AdamMulti mt;
     mt.n = 0; mt.first_block[0] = 0;
     for (int t = 0; t < n_tensors; ++t) {
         if (numel[t] == 0) continue;
         if (!params[t] || !grads[t] || !exp_avgs[t] || !exp_avg_sqs[t] || !lrs[t] || !states[t])
-            return ggs_fail_(GGS_ERR_ARG, "ggs_adam_step_multi: NULL tensor pointer");
+            return ggs_fail_(GGS_ERR_ARG, "%s: NULL tensor pointer", who);
         if (!aligned16(params[t]) || !aligned16(grads[t]) || !aligned16(exp_avgs[t]) || !aligned16(exp_avg_sqs[t]))
-            return ggs_fail_(GGS_ERR_ARG, "ggs_adam_step_multi: tensors must be 16-byte aligned");
+            return ggs_fail_(GGS_ERR_ARG, "%s: tensors must be 16-byte aligned", who);
         const int k = mt.n++;
         mt.numel[k] = numel[t]; mt.p[k] = params[t]; mt.g[k] = grads[t]; mt.m[k] = exp_avgs[t]; mt.v[k] = exp_avg_sqs[t];
-        mt.lr[k] = lrs[t]; mt.s[k] = static_cast<const AdamState*>(states[t]);
+        mt.lr[k] = lrs[t]; mt.s[k] = static_cast<AdamState*>(states[t]);
         size_t blocks = (numel[t] / 4 + 255) / 256;
         blocks = blocks < 1 ? 1 : (blocks > 1024 ? 1024 : blocks);
         mt.first_block[k + 1] = mt.first_block[k] + (unsigned)blocks;
@@ -207,11 +219,28 @@ int ggs_adam_step_multi(int n_tensors, const size_t* numel, float* const* params
     if (mt.n == 0) return GGS_OK;
     mt.guard = static_cast<const unsigned long long*>(guard);
     mt.beta1 = (float)beta1; mt.beta2 = (float)beta2; mt.omb1 = (float)(1.0 - beta1); mt.omb2 = (float)(1.0 - beta2);
-    mt.eps = (float)eps;
-    hipLaunchKernelGGL(k_adam_multi, dim3(mt.first_block[mt.n]), dim3(256), 0, (hipStream_t)stream, mt);
+    mt.eps = (float)eps; mt.beta1d = beta1; mt.beta2d = beta2;
+    if (tick) hipLaunchKernelGGL(k_adam_tick_multi_step, dim3(mt.first_block[mt.n]), dim3(256), 0, (hipStream_t)stream, mt);
+    else hipLaunchKernelGGL(k_adam_multi, dim3(mt.first_block[mt.n]), dim3(256), 0, (hipStream_t)stream, mt);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "adam_step_multi launch failed: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "%s: launch failed: %s", who, hipGetErrorString(e));
     return GGS_OK;
+}
+
+int ggs_adam_step_multi(int n_tensors, const size_t* numel, float* const* params, const float* const* grads,
+                        float* const* exp_avgs, float* const* exp_avg_sqs, const float* const* lrs,
+                        const void* const* states, double beta1, double beta2, double eps, const void* guard,
+                        void* stream) {
+    return adam_step_multi(false, "ggs_adam_step_multi", n_tensors, numel, params, grads, exp_avgs, exp_avg_sqs, lrs,
+                           const_cast<void* const*>(states), beta1, beta2, eps, guard, stream);
+}
+// ggs_adam_tick_multi + ggs_adam_step_multi in ONE launch (tensors given once each: a state is advanced once per call).
+int ggs_adam_tick_step_multi(int n_tensors, const size_t* numel, float* const* params, const float* const* grads,
+                             float* const* exp_avgs, float* const* exp_avg_sqs, const float* const* lrs,
+                             void* const* states, double beta1, double beta2, double eps, const void* guard,
+                             void* stream) {
+    return adam_step_multi(true, "ggs_adam_tick_step_multi", n_tensors, numel, params, grads, exp_avgs, exp_avg_sqs, lrs,
+                           states, beta1, beta2, eps, guard, stream);
 }
 
 }  // extern "C"

@@ -209,6 +209,32 @@ int ggs_count_blends(const GgsParams* p, const void* geom, const void* bin, size
     return check("count_blends", s, p->debug);
 }
 
+// Leading bytes of `bin` / of the backward's scratch that ggs_forward* / ggs_backward zero-fill first (what a
+// ggs_step_prologue must list to take those two launches over).
+int ggs_step_clear_plan(const GgsParams* p, size_t bin_capacity, size_t* bin_bytes, size_t* backward_scratch_bytes) {
+    g_err[0] = 0;
+    GGS_TRY(check_params(p));
+    if (!bin_bytes || !backward_scratch_bytes) return fail(GGS_ERR_ARG, "ggs_step_clear_plan: NULL output pointer");
+    const Dims d = dims(p);
+    *bin_bytes = ggs_bin_layout(p->n_views, d.T, bin_capacity).zero_bytes;
+    *backward_scratch_bytes = (size_t)p->n_views * (size_t)p->P * sizeof(GradRec);
+    return GGS_OK;
+}
+
+// Device address of page-locked host memory (hipHostMalloc / hipHostRegister with the mapped flag: what PyTorch's pinned
+// tensors are), for kernels that read or write a small per-iteration block in place instead of behind a copy launch.
+int ggs_host_mapped_pointer(void* host_ptr, void** device_ptr) {
+    g_err[0] = 0;
+    if (!host_ptr || !device_ptr) return fail(GGS_ERR_ARG, "ggs_host_mapped_pointer: NULL argument");
+    *device_ptr = nullptr;
+    const hipError_t e = hipHostGetDevicePointer(device_ptr, host_ptr, 0);
+    if (e != hipSuccess || !*device_ptr) {
+        (void)hipGetLastError();
+        return fail(GGS_ERR_HIP, "ggs_host_mapped_pointer: not mapped page-locked memory: %s", hipGetErrorString(e));
+    }
+    return GGS_OK;
+}
+
 size_t ggs_backward_scratch_bytes(const GgsParams* p) {
     if (!p || p->P < 0 || p->n_views <= 0) return 0;
     const int splits = bwd_splits(p);
@@ -229,8 +255,31 @@ __global__ __launch_bounds__(256) void k_zero(uint32_t* p, size_t n_words, size_
 }
 }  // namespace
 
+// Pre-clear marks (ggs_step_prologue, include/ggsplat.h): ranges the prologue launch of this host thread has already
+// zero-filled on a stream.  A fill of exactly such a range (same stream, same start, no longer) consumes the mark instead of
+// launching -- every zero fill of the library goes through ggs_zero_async, so the consumers need no flag.
+namespace {
+struct ClearMark { hipStream_t s; char* p; size_t bytes; };
+thread_local ClearMark g_marks[GGS_PROLOGUE_MAX_CLEAR];
+thread_local int g_n_marks = 0;
+bool take_mark(void* ptr, size_t bytes, hipStream_t s) {
+    for (int i = 0; i < g_n_marks; ++i)
+        if (g_marks[i].s == s && g_marks[i].p == (char*)ptr && bytes <= g_marks[i].bytes) {
+            g_marks[i] = g_marks[--g_n_marks];
+            return true;
+        }
+    return false;
+}
+}  // namespace
+void ggs_set_clear_marks_(int n, void* const* ptrs, const size_t* bytes, hipStream_t s) {
+    g_n_marks = 0;                                                      // marks nobody consumed are dropped here
+    for (int i = 0; i < n && i < GGS_PROLOGUE_MAX_CLEAR; ++i)
+        if (ptrs[i] && bytes[i]) g_marks[g_n_marks++] = ClearMark{s, (char*)ptrs[i], bytes[i]};
+}
+
 hipError_t ggs_zero_async(void* ptr, size_t bytes, hipStream_t s) {
     if (bytes == 0) return hipSuccess;
+    if (g_n_marks && take_mark(ptr, bytes, s)) return hipSuccess;
     if ((reinterpret_cast<uintptr_t>(ptr) & 3) || (bytes & 3)) return hipErrorInvalidValue;
     const size_t n_words = bytes / 4;
     size_t head = ((16 - (reinterpret_cast<uintptr_t>(ptr) & 15)) & 15) / 4;

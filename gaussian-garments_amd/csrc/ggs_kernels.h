@@ -126,6 +126,25 @@ __global__ void ggs_k_preprocess_bwd_sh2(PreBwdArgs a);
 __global__ void ggs_k_preprocess_bwd_sh3(PreBwdArgs a);
 __global__ void ggs_k_reduce_partials(PreBwdArgs a, int splits);
 
+// Optimiser state of one tensor (ggs_adam.hip; advanced by its tick kernels, by the update kernel that ticks itself, or by the
+// last kernel of ggs_registration_aux_tail).
+// 40 bytes, device.  `ticket` counts the workgroups of ggs_adam_tick_step_multi that are done with this tensor (back to 0
+// when the launch ends); everything in front of it is the state a checkpoint keeps.
+struct AdamState { long long step; float bias1; float bias2_sqrt; double pow1; double pow2; unsigned ticket; unsigned pad; };
+
+__device__ __forceinline__ void ggs_adam_tick_one(AdamState* s, double beta1, double beta2) {
+    const long long t = s->step + 1;
+    s->step = t;
+    // beta^t as a running double product (torch evaluates beta ** step in Python floats each step; the products agree to
+    // ~t * 2^-53, far below the fp32 the corrections are used in) -- a device-side pow() made this one-thread kernel
+    // the slowest launch of a graph-replayed iteration after the rasterizer and the loss
+    const double p1 = t == 1 ? beta1 : s->pow1 * beta1, p2 = t == 1 ? beta2 : s->pow2 * beta2;
+    s->pow1 = p1; s->pow2 = p2;
+    s->bias1 = (float)(1.0 - p1);
+    s->bias2_sqrt = (float)sqrt(1.0 - p2);
+}
+
+
 // host-side error plumbing (ggs_api.hip)
 int ggs_fail_(int code, const char* fmt, ...);
 void ggs_clear_error_();
@@ -135,3 +154,5 @@ void ggs_clear_error_();
 // every entry point must behave identically whether it is launched eagerly or replayed from a graph.
 // p must be 4-byte aligned, bytes a multiple of 4.  Returns hipSuccess / the launch error.
 hipError_t ggs_zero_async(void* p, size_t bytes, hipStream_t s);
+// ggs_step_prologue's marks: ranges already zero-filled on `s` by this host thread; ggs_zero_async consumes them (ggs_api.hip)
+void ggs_set_clear_marks_(int n, void* const* ptrs, const size_t* bytes, hipStream_t s);

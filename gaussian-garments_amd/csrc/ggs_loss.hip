@@ -8,15 +8,16 @@
 // which costs 5 grouped conv2d forward + their backward (~10x the image bytes, milliseconds at 1080p --
 // several times the HIP rasterizer's forward+backward).  Here:
 //   pass A (ggs_k_loss_stats): x = img*mask and y = gt*mask (zero padded like conv2d(padding=5)); separable 11-tap
-//           window (same fp32 taps as create_window) gives mu1, mu2, E[xx], E[yy], E[xy]; the SSIM map value and
-//           its three partial derivatives (d/dmu1 total, d/dE[xx], d/dE[xy]) are formed per pixel; workgroup-reduced
-//           sums of |x - y| and of the map go to sums[v] (one atomic pair per workgroup).
+//           window (same fp32 taps as create_window) gives mu1, mu2, E[xx + yy], E[xy] -- FOUR filtered maps, not five: the
+//           SSIM map needs sigma1^2 + sigma2^2 = E[xx] + E[yy] - mu1^2 - mu2^2 only as a sum, and d/dE[xx] = d/dE[yy] -- the
+//           SSIM map value and its three partial derivatives (d/dmu1 total, d/dE[xx], d/dE[xy]) are formed per pixel;
+//           workgroup-reduced sums of |x - y| and of the map go to sums[v] (one atomic pair per workgroup).
 //   pass B (ggs_k_loss_grad): the three derivative maps are filtered with the same (symmetric) window:
 //           dSSIM/dx = G*dmu1 + 2 x (G*dExx) + y (G*dExy); combined with the L1 sign term and the mask.
 // Both passes stream rows through one wave per 64-column strip (see below): the horizontal filter reads a wave-private
 // LDS row, the vertical filter is a ring of partial sums in registers.
 // Roofline: HBM for the batched call (A: reads 24 B/px(+mask) writes 36 B/px; B: reads 60 B/px writes 12 B/px ~ 270 MB
-// per 1080p view; B moves ~4.8 TB/s at 32 views), VALU for pass A (~215 instructions per pixel row and lane).
+// per 1080p view; B moves ~4.8 TB/s at 32 views); pass A is bound by the latency of its row steps (see GGS_LOSS_WAVES).
 #include "ggs_kernels.h"
 
 namespace {
@@ -82,17 +83,33 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
 // output rows they belong to; the output row that received its last tap is finished (SSIM value + derivative maps).
 // Taps are accumulated in the order 0..10 in both directions.  Against round 1's 32x32 LDS tiles (five intermediate maps
 // = 27 KB per tile, 3 workgroups per CU, three barriers per channel) there are no workgroup barriers, no LDS round trip of
-// the intermediate maps and ~1 KB of LDS per wave: occupancy is set by the registers alone (pass A: 128 VGPRs, 4 waves per
-// SIMD; 32 views 1.84 -> 1.54 ms and 1.61 -> 1.40 ms, one view 76 -> 56 us and 56 -> 42 us).  The ring index is static because the row loop is unrolled by 11.
+// the intermediate maps and ~2.4 KB of LDS per wave: occupancy is set by the registers alone (pass A: 3 waves per SIMD, see
+// GGS_LOSS_WAVES below; 32 views 1.84 -> 1.54 ms and 1.61 -> 1.40 ms, one view 76 -> 56 us and 56 -> 42 us in round 2).  The ring index is static because the row loop is unrolled by 11.
 // Memory pipeline of a step: park the row loaded during the previous step -> write the previous step's outputs -> start
 // the loads of the next row -> filter.  Loads are branch-free (clamped addresses, padding applied at park time) and the
 // stores are issued BEFORE the loads that the next step waits for: vmcnt retires in order, so a store issued after
 // them would put its whole write latency on the critical path of every step.
+// Build switches of pass A (A/B libraries: tools/dbg/build_variant.sh with ALL_EXTRA="-DGGS_LOSS_WAVES=4 ..."): waves per SIMD
+// the register allocation aims at, and how many input rows ahead of the one being filtered the loads run.  The pass is bound
+// by the LATENCY of a row step (load -> LDS -> 44 reads -> filter -> SSIM chain), not by its instruction count: going from
+// five maps / 215 VALU per row to four / 167 changed nothing at 4 waves per SIMD, where 15-28 registers spill into the
+// chain (scratch round trips); 3 waves without spills and loads two rows ahead measure, us per 1080p view (tools/dbg/time_loss.py,
+// one view | 16 views):  round 3 kernel 69 | 59;  4 waves, 1 row ahead 65 | 57;  3 waves, 1 ahead 61 | 57;  4 waves, 2 ahead 76 | 71;
+// 2 waves, 2 ahead 69 | 56;  **3 waves, 2 ahead 54 | 50.5** (region-of-interest form 55 | 36).
+#ifndef GGS_LOSS_WAVES
+#define GGS_LOSS_WAVES 3
+#endif
+#ifndef GGS_LOSS_AHEAD
+#define GGS_LOSS_AHEAD 2
+#endif
+#ifndef GGS_LOSS_SPLIT_READS                         // 1: at most 22 LDS values in flight (what 128 VGPRs hold without spilling more)
+#define GGS_LOSS_SPLIT_READS (GGS_LOSS_WAVES >= 4)
+#endif
 #define LS_COLS 64
 #define LS_HB 34                          // LS_HB + 2 LH = 44 input rows = 4 x 11.  (12-row bands for single-view launches --
                                           // 2.8x the waves, half the dependent row steps each, 1.8x the filtered rows --
-                                          // measured 0.166 against 0.104 ms per 1080p view: the pass is bound by its VALU
-                                          // work per row, not by the latency of a row step.)
+                                          // measured 0.166 against 0.104 ms per 1080p view in round 2: the waves no longer
+                                          // fit in one round of the chip, two rounds of 22 steps are no shorter than one of 44.)
 #define LS_HB_ROI 12                      // band height of pass B in the region-of-interest form (see any_tile)
 #define LS_IN (LS_COLS + 2 * LH)          // 74
 #define LS_WAVES 4                        // waves per workgroup: consecutive bands of one strip
@@ -112,8 +129,10 @@ __device__ __forceinline__ void ring_add(RowRing<NM>& ring, const float (&h)[NM]
     }
 }
 
-// addresses of the two input columns of a lane in input row y, clamped into the image (ok = not padding)
-struct RowAddr { size_t p1, p2; bool ok1, ok2; };
+// BYTE offsets of the two input columns of a lane in input row y within one image plane, clamped into the image (ok = not
+// padding).  32-bit: a plane base is wave-uniform, so every access is "scalar base + 32-bit lane offset" -- as size_t
+// indices the per-lane address arithmetic was ~17 64-bit VALU instructions per row step (loss_args bounds 12 H W < 2^32).
+struct RowAddr { uint32_t p1, p2; bool ok1, ok2; };
 __device__ __forceinline__ RowAddr row_addr(int y, int H, int W, int ox, int lane) {
     const int c1 = ox - LH + lane, c2 = ox + LS_COLS - LH + lane;
     const bool has2 = lane < 2 * LH;
@@ -121,10 +140,20 @@ __device__ __forceinline__ RowAddr row_addr(int y, int H, int W, int ox, int lan
     RowAddr r;
     r.ok1 = oky && c1 >= 0 && c1 < W;
     r.ok2 = oky && has2 && c2 < W;
-    const size_t row = (size_t)min(max(y, 0), H - 1) * W;
-    r.p1 = row + min(max(c1, 0), W - 1);
-    r.p2 = row + min(max(has2 ? c2 : c1, 0), W - 1);
+    const uint32_t row = (uint32_t)min(max(y, 0), H - 1) * (uint32_t)W;
+    r.p1 = (row + (uint32_t)min(max(c1, 0), W - 1)) * 4u;
+    r.p2 = (row + (uint32_t)min(max(has2 ? c2 : c1, 0), W - 1)) * 4u;
     return r;
+}
+// (The explicit global address space matters for the image pointers that are LOADED from the pointer tables: the compiler
+// cannot infer it for them and then forms 64-bit per-lane addresses instead of "global_load v, v_off, s[base]".)
+typedef const __attribute__((address_space(1))) char* gbytes;
+typedef __attribute__((address_space(1))) char* gbytes_w;
+__device__ __forceinline__ float ld_off(const float* base, uint32_t byte_off) {
+    return *(const __attribute__((address_space(1))) float*)((gbytes)base + byte_off);
+}
+__device__ __forceinline__ void st_off(float* base, uint32_t byte_off, float v) {
+    *(__attribute__((address_space(1))) float*)((gbytes_w)base + byte_off) = v;
 }
 
 struct StatsRow { float x1, y1, m1, x2, y2, m2; bool ok1, ok2; };       // raw values of the next input row
@@ -134,65 +163,89 @@ __device__ __forceinline__ StatsRow stats_load_row(const float* __restrict__ img
     const RowAddr ad = row_addr(y, H, W, ox, lane);
     StatsRow r;
     r.ok1 = ad.ok1; r.ok2 = ad.ok2;
-    r.x1 = img[ad.p1]; r.y1 = gt[ad.p1]; r.m1 = MASK ? mask[ad.p1] : 1.f;
-    r.x2 = img[ad.p2]; r.y2 = gt[ad.p2]; r.m2 = MASK ? mask[ad.p2] : 1.f;
+    r.x1 = ld_off(img, ad.p1); r.y1 = ld_off(gt, ad.p1); r.m1 = MASK ? ld_off(mask, ad.p1) : 1.f;
+    r.x2 = ld_off(img, ad.p2); r.y2 = ld_off(gt, ad.p2); r.m2 = MASK ? ld_off(mask, ad.p2) : 1.f;
     return r;
 }
 
 struct StatsCtx {
     const float *img, *gt, *mask;
     float* dm;                // null: the maps of this box are not needed (region-of-interest form)
+    float *dm1, *dm2;         // dm + HW, dm + 2 HW
     int H, W, oy, ox, lane;
     size_t HW;
-    float (*sx)[LS_IN];       // [2][LS_IN] wave-private
+    float (*sx)[LS_IN];       // [2][LS_IN] wave-private: x, y, x x + y y, x y of the current input row
     float (*sy)[LS_IN];
+    float (*ss)[LS_IN];
+    float (*sp)[LS_IN];
     float l1, ssum;
     StatsRow nxt;
+#if GGS_LOSS_AHEAD == 2
+    StatsRow nxt2;            // the row after `nxt`, in flight
+#endif
     float o0, o1, o2;         // outputs of the previous step, written at the start of this one
     bool pend;
 };
 
 template <int R, bool MASK>
-__device__ __forceinline__ void stats_step(StatsCtx& c, RowRing<5>& ring, int i) {
+__device__ __forceinline__ void stats_step(StatsCtx& c, RowRing<4>& ring, int i) {
     const int buf = i & 1;
     const int lane = c.lane;
     const int x = c.ox + lane;
-    c.sx[buf][lane] = c.nxt.ok1 ? c.nxt.x1 * c.nxt.m1 : 0.f; c.sy[buf][lane] = c.nxt.ok1 ? c.nxt.y1 * c.nxt.m1 : 0.f;
+    {   // the products are formed ONCE per input pixel here, not once per tap in the 11 lanes that filter it
+        const float xv = c.nxt.ok1 ? c.nxt.x1 * c.nxt.m1 : 0.f, yv = c.nxt.ok1 ? c.nxt.y1 * c.nxt.m1 : 0.f;
+        c.sx[buf][lane] = xv; c.sy[buf][lane] = yv;
+        c.ss[buf][lane] = fmaf(xv, xv, yv * yv); c.sp[buf][lane] = xv * yv;
+    }
     if (lane < 2 * LH) {
-        c.sx[buf][LS_COLS + lane] = c.nxt.ok2 ? c.nxt.x2 * c.nxt.m2 : 0.f;
-        c.sy[buf][LS_COLS + lane] = c.nxt.ok2 ? c.nxt.y2 * c.nxt.m2 : 0.f;
+        const float xv = c.nxt.ok2 ? c.nxt.x2 * c.nxt.m2 : 0.f, yv = c.nxt.ok2 ? c.nxt.y2 * c.nxt.m2 : 0.f;
+        c.sx[buf][LS_COLS + lane] = xv; c.sy[buf][LS_COLS + lane] = yv;
+        c.ss[buf][LS_COLS + lane] = fmaf(xv, xv, yv * yv); c.sp[buf][LS_COLS + lane] = xv * yv;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     if (c.pend && c.dm) {                                                // output row i - 1 - 2 LH
-        const size_t p = (size_t)(c.oy + i - 1 - 2 * LH) * c.W + x;
-        c.dm[p] = c.o0; c.dm[c.HW + p] = c.o1; c.dm[2 * c.HW + p] = c.o2;
+        const uint32_t p = ((uint32_t)(c.oy + i - 1 - 2 * LH) * (uint32_t)c.W + (uint32_t)x) * 4u;
+        st_off(c.dm, p, c.o0); st_off(c.dm1, p, c.o1); st_off(c.dm2, p, c.o2);
     }
+#if GGS_LOSS_AHEAD == 2
+    c.nxt = c.nxt2;
+    c.nxt2 = stats_load_row<MASK>(c.img, c.gt, c.mask, c.oy - LH + i + 2, c.H, c.W, c.ox, lane);
+#else
     c.nxt = stats_load_row<MASK>(c.img, c.gt, c.mask, c.oy - LH + i + 1, c.H, c.W, c.ox, lane);
-    float xs[11], ys[11];
+#endif
+    // two maps at a time (22 values in flight, not 44: the ring of vertical partial sums already holds 44 registers)
+    float h[4] = {0.f, 0.f, 0.f, 0.f};
+    {
+        float xs[11], ys[11];
 #pragma unroll
-    for (int k = 0; k < 11; ++k) { xs[k] = c.sx[buf][lane + k]; ys[k] = c.sy[buf][lane + k]; }
+        for (int k = 0; k < 11; ++k) { xs[k] = c.sx[buf][lane + k]; ys[k] = c.sy[buf][lane + k]; }
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { h[0] = fmaf(G11[k], xs[k], h[0]); h[1] = fmaf(G11[k], ys[k], h[1]); }
+        // L1 over the strip's own pixels (the row is an own row when LH <= i < LH + LS_HB)
+        if (i >= LH && i < LH + LS_HB && c.oy + i - LH < c.H && x < c.W) c.l1 += fabsf(xs[LH] - ys[LH]);
+    }
+#if GGS_LOSS_SPLIT_READS
+    asm volatile("" ::: "memory");                   // keeps the second group's LDS reads behind the first group's use
+#endif
+    {
+        float sq[11], pr[11];
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { sq[k] = c.ss[buf][lane + k]; pr[k] = c.sp[buf][lane + k]; }
+#pragma unroll
+        for (int k = 0; k < 11; ++k) { h[2] = fmaf(G11[k], sq[k], h[2]); h[3] = fmaf(G11[k], pr[k], h[3]); }
+    }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    float h[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 11; ++k) {
-        const float g = G11[k], xv = xs[k], yv = ys[k];
-        h[0] = fmaf(g, xv, h[0]); h[1] = fmaf(g, yv, h[1]);
-        h[2] = fmaf(g, xv * xv, h[2]); h[3] = fmaf(g, yv * yv, h[3]); h[4] = fmaf(g, xv * yv, h[4]);
-    }
-    // L1 over the strip's own pixels (the row is an own row when LH <= i < LH + LS_HB)
-    if (i >= LH && i < LH + LS_HB && c.oy + i - LH < c.H && x < c.W) c.l1 += fabsf(xs[LH] - ys[LH]);
-    ring_add<5, R>(ring, h);
+    ring_add<4, R>(ring, h);
     const int o = i - 2 * LH;                       // the output row that just received tap 10
     c.pend = o >= 0 && c.oy + o < c.H && x < c.W;
     {
         constexpr int slot = (R + 1) % 11;
-        const float m1 = ring.v[slot][0], m2 = ring.v[slot][1], e11 = ring.v[slot][2], e22 = ring.v[slot][3],
-                    e12 = ring.v[slot][4];
-        const float v1 = e11 - m1 * m1, v2 = e22 - m2 * m2, cv = e12 - m1 * m2;
+        const float m1 = ring.v[slot][0], m2 = ring.v[slot][1], ess = ring.v[slot][2], e12 = ring.v[slot][3];
+        const float mm = m1 * m1 + m2 * m2, cv = e12 - m1 * m2;          // ess - mm = sigma1^2 + sigma2^2
         const float A1 = 2.f * m1 * m2 + SSIM_C1, A2 = 2.f * cv + SSIM_C2;
-        const float B1 = m1 * m1 + m2 * m2 + SSIM_C1, B2 = v1 + v2 + SSIM_C2;
+        const float B1 = mm + SSIM_C1, B2 = (ess - mm) + SSIM_C2;
         const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
         const float inv = iB1 * iB2;
         const float S = A1 * A2 * inv;
@@ -214,12 +267,11 @@ __device__ __forceinline__ void unroll11(Ctx& c, Ring& ring, int i0) {
 }
 template <bool MASK>
 struct StatsStep {
-    template <int R> static __device__ __forceinline__ void run(StatsCtx& c, RowRing<5>& r, int i) { stats_step<R, MASK>(c, r, i); }
+    template <int R> static __device__ __forceinline__ void run(StatsCtx& c, RowRing<4>& r, int i) { stats_step<R, MASK>(c, r, i); }
 };
 
 template <bool MASK>
-__device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float (*s_x)[2][LS_IN], float (*s_y)[2][LS_IN],
-                                                       float* s_red) {
+__device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float (*s_x)[4][2][LS_IN], float* s_red) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int v = blockIdx.z / 3, ch = blockIdx.z % 3;
     const int band = blockIdx.y * LS_WAVES + wave;
@@ -228,24 +280,27 @@ __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float 
     c.img = a.img + ((size_t)v * 3 + ch) * HW;
     c.gt = a.gt_tab ? a.gt_tab[v] + (size_t)ch * HW : a.gt + ((size_t)v * 3 + ch) * HW;
     c.mask = !MASK ? nullptr : a.mask_tab ? a.mask_tab[v] : a.mask + (size_t)v * HW;
-    c.dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW;
+    c.dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW; c.dm1 = c.dm + HW; c.dm2 = c.dm + 2 * HW;
     c.H = a.H; c.W = a.W; c.oy = band * LS_HB; c.ox = blockIdx.x * LS_COLS; c.lane = lane; c.HW = HW;
-    c.sx = s_x[wave]; c.sy = s_y[wave];
+    c.sx = s_x[wave][0]; c.sy = s_x[wave][1]; c.ss = s_x[wave][2]; c.sp = s_x[wave][3];
     c.l1 = 0.f; c.ssum = 0.f; c.pend = false; c.o0 = c.o1 = c.o2 = 0.f;
     if (a.tile_count && c.oy < a.H &&
         !any_tile(a, v, c.ox - LS_COLS, c.oy - (LH + LS_HB_ROI - 1), c.ox + 2 * LS_COLS - 1, c.oy + LS_HB - 1 + LH + LS_HB_ROI - 1, lane))
         c.dm = nullptr;
     if (c.oy < a.H) {
-        RowRing<5> ring;
+        RowRing<4> ring;
 #pragma unroll
         for (int j = 0; j < 11; ++j)
 #pragma unroll
-            for (int m = 0; m < 5; ++m) ring.v[j][m] = 0.f;
+            for (int m = 0; m < 4; ++m) ring.v[j][m] = 0.f;
         c.nxt = stats_load_row<MASK>(c.img, c.gt, c.mask, c.oy - LH, c.H, c.W, c.ox, lane);
+#if GGS_LOSS_AHEAD == 2
+        c.nxt2 = stats_load_row<MASK>(c.img, c.gt, c.mask, c.oy - LH + 1, c.H, c.W, c.ox, lane);
+#endif
         for (int i0 = 0; i0 < LS_HB + 2 * LH; i0 += 11) unroll11<0, StatsStep<MASK>>(c, ring, i0);
         if (c.pend && c.dm) {                                            // the last output row
-            const size_t p = (size_t)(c.oy + LS_HB - 1) * c.W + c.ox + lane;
-            c.dm[p] = c.o0; c.dm[HW + p] = c.o1; c.dm[2 * HW + p] = c.o2;
+            const uint32_t p = ((uint32_t)(c.oy + LS_HB - 1) * (uint32_t)c.W + (uint32_t)(c.ox + lane)) * 4u;
+            st_off(c.dm, p, c.o0); st_off(c.dm1, p, c.o1); st_off(c.dm2, p, c.o2);
         }
     }
     const float l1 = block_sum(c.l1, s_red), ssum = block_sum(c.ssum, s_red);
@@ -259,16 +314,16 @@ __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float 
 
 // Pass A: grid (ceil(W/64), ceil(ceil(H/34)/4), V*3), block 256 = 4 independent waves.
 // (Masked and unmasked forms are separate kernels: as two branches of one kernel the register allocation of the shared
-// prologue pushed the masked body over its 128 VGPRs -- 8 spilled registers, 32 B of scratch per lane.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ggs_k_loss_stats(LossArgs a) {
-    __shared__ float s_x[LS_WAVES][2][LS_IN], s_y[LS_WAVES][2][LS_IN];
+// prologue pushed the masked body over its register budget.)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GGS_LOSS_WAVES, GGS_LOSS_WAVES))) void ggs_k_loss_stats(LossArgs a) {
+    __shared__ float s_x[LS_WAVES][4][2][LS_IN];
     __shared__ float s_red[4];
-    loss_stats_stream_body<false>(a, s_x, s_y, s_red);
+    loss_stats_stream_body<false>(a, s_x, s_red);
 }
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void ggs_k_loss_stats_masked(LossArgs a) {
-    __shared__ float s_x[LS_WAVES][2][LS_IN], s_y[LS_WAVES][2][LS_IN];
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GGS_LOSS_WAVES, GGS_LOSS_WAVES))) void ggs_k_loss_stats_masked(LossArgs a) {
+    __shared__ float s_x[LS_WAVES][4][2][LS_IN];
     __shared__ float s_red[4];
-    loss_stats_stream_body<true>(a, s_x, s_y, s_red);
+    loss_stats_stream_body<true>(a, s_x, s_red);
 }
 
 namespace {
@@ -282,10 +337,11 @@ __device__ __forceinline__ GradRow grad_load_row(const float* __restrict__ dm, c
     const RowAddr ad = row_addr(y, H, W, ox, lane);
     GradRow r;
     r.ok1 = ad.ok1; r.ok2 = ad.ok2;
-    r.a1 = dm[ad.p1]; r.b1 = dm[HW + ad.p1]; r.c1 = dm[2 * HW + ad.p1];
-    r.a2 = dm[ad.p2]; r.b2 = dm[HW + ad.p2]; r.c2 = dm[2 * HW + ad.p2];
-    const size_t po = (size_t)min(max(yo, 0), H - 1) * W + min(ox + lane, W - 1);
-    r.xo = img[po]; r.yo = gt[po]; r.mo = MASK ? mask[po] : 1.f;
+    const float *dm1 = dm + HW, *dm2 = dm + 2 * HW;
+    r.a1 = ld_off(dm, ad.p1); r.b1 = ld_off(dm1, ad.p1); r.c1 = ld_off(dm2, ad.p1);
+    r.a2 = ld_off(dm, ad.p2); r.b2 = ld_off(dm1, ad.p2); r.c2 = ld_off(dm2, ad.p2);
+    const uint32_t po = ((uint32_t)min(max(yo, 0), H - 1) * (uint32_t)W + (uint32_t)min(ox + lane, W - 1)) * 4u;
+    r.xo = ld_off(img, po); r.yo = ld_off(gt, po); r.mo = MASK ? ld_off(mask, po) : 1.f;
     return r;
 }
 struct GradCtx {
@@ -312,7 +368,7 @@ __device__ __forceinline__ void grad_step(GradCtx& c, RowRing<3>& ring, int i) {
     const float xo = c.nxt.xo, yo = c.nxt.yo, mo = c.nxt.mo;          // image at this step's output pixel
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (c.pend) c.out[(size_t)(c.oy + i - 1 - 2 * LH) * c.W + x] = c.o0;
+    if (c.pend) st_off(c.out, ((uint32_t)(c.oy + i - 1 - 2 * LH) * (uint32_t)c.W + (uint32_t)x) * 4u, c.o0);
     c.nxt = grad_load_row<MASK>(c.dm, c.img, c.gt, c.mask, c.HW, c.oy - LH + i + 1, c.oy + i + 1 - 2 * LH, c.H, c.W, c.ox, lane);
     float d[3][11];
 #pragma unroll
@@ -403,6 +459,7 @@ static int loss_args(LossArgs& a, int n_views, int H, int W, const float* img, c
     if (n_views <= 0 || H <= 0 || W <= 0) return ggs_fail_(GGS_ERR_ARG, "%s: bad sizes", who);
     if (!img || !(gt || gt_tab) || !scratch) return ggs_fail_(GGS_ERR_ARG, "%s: NULL pointer argument", who);
     if ((size_t)n_views * 3 > 65535) return ggs_fail_(GGS_ERR_SIZE, "%s: n_views too large", who);
+    if ((size_t)H * W * 12 >= ((size_t)1 << 32)) return ggs_fail_(GGS_ERR_SIZE, "%s: image too large (12 H W must fit 32 bits)", who);
     a.V = n_views; a.H = H; a.W = W; a.img = img; a.gt = gt; a.mask = mask; a.gt_tab = gt_tab; a.mask_tab = mask_tab;
     a.inv_n = 1.f / (3.f * (float)H * (float)W);
     a.w = nullptr; a.sums = nullptr; a.dL_dimg = nullptr; a.dmap = (float*)scratch;

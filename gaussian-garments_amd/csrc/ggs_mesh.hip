@@ -143,9 +143,7 @@ __device__ __forceinline__ void quat_chain(const Frame& F, const float raw[4], Q
     Q.qwn = normalize4(Q.qw, Q.rot);
 }
 
-__global__ __launch_bounds__(256) void k_mesh_fwd(MeshArgs a) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.P) return;
+__device__ __forceinline__ void mesh_fwd_one(const MeshArgs& a, int i) {
     Frame F;
     int64_t idx[3];
     face_frame(a.verts, a.faces, a.binding[i], F, idx);
@@ -166,6 +164,38 @@ __global__ __launch_bounds__(256) void k_mesh_fwd(MeshArgs a) {
     QuatChain Q;
     quat_chain(F, raw, Q);
     reinterpret_cast<float4*>(a.rotation)[i] = make_float4(Q.rot[0], Q.rot[1], Q.rot[2], Q.rot[3]);
+}
+__global__ __launch_bounds__(256) void k_mesh_fwd(MeshArgs a) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < a.P) mesh_fwd_one(a, i);
+}
+
+// ggs_step_prologue: the jobs at the head of an optimisation step that depend on nothing computed in it -- zero fills, the
+// per-iteration parameter block, the opacity activation, the mesh binding -- as ONE launch.  A graph-replayed s2 iteration
+// spent ~45 us (of 415) in eight such launches of 1-5 us of work each: a dependent launch costs ~5 us whatever it does.
+struct PrologueArgs {
+    MeshArgs mesh;                                   // P = 0: no binding
+    int n_op; const float* op_logit; float* op;
+    int n_clear; uint32_t* clr[GGS_PROLOGUE_MAX_CLEAR]; size_t clr_words[GGS_PROLOGUE_MAX_CLEAR];
+    const uint32_t* copy_src; uint32_t* copy_dst; int copy_words;
+};
+__global__ __launch_bounds__(256) void k_step_prologue(PrologueArgs a) {
+    const size_t gi = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+    if (blockIdx.x == gridDim.x - 1)
+        for (int i = threadIdx.x; i < a.copy_words; i += 256) a.copy_dst[i] = a.copy_src[i];
+    for (int c = 0; c < a.n_clear; ++c) {
+        uint32_t* p = a.clr[c];
+        const size_t n = a.clr_words[c];
+        size_t head = ((16 - (reinterpret_cast<uintptr_t>(p) & 15)) & 15) / 4;     // words in front of the 16-byte boundary
+        head = head < n ? head : n;
+        const size_t n_vec = (n - head) / 4, tail0 = head + n_vec * 4;
+        uint4* v = reinterpret_cast<uint4*>(p + head);
+        for (size_t k = gi; k < n_vec; k += stride) v[k] = make_uint4(0, 0, 0, 0);
+        if (gi < head) p[gi] = 0;
+        if (gi < n - tail0) p[tail0 + gi] = 0;
+    }
+    if (gi < (size_t)a.n_op) a.op[gi] = 1.f / (1.f + expf(-a.op_logit[gi]));        // torch.sigmoid's expression
+    if (gi < (size_t)a.mesh.P) mesh_fwd_one(a.mesh, (int)gi);
 }
 
 // Vertex gradients: the 256 Gaussians of a workgroup are neighbours on the mesh, so the vertices they touch usually span a
@@ -346,6 +376,53 @@ int ggs_mesh_bind_forward(int P, int F, const float* verts, const int64_t* faces
     hipLaunchKernelGGL(k_mesh_fwd, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "mesh_fwd launch failed: %s", hipGetErrorString(e));
+    return GGS_OK;
+}
+
+int ggs_step_prologue(const GgsStepPrologue* d, void* stream) {
+    ggs_clear_error_();
+    if (!d) return ggs_fail_(GGS_ERR_ARG, "ggs_step_prologue: NULL descriptor");
+    if (d->n_clear < 0 || d->n_clear > GGS_PROLOGUE_MAX_CLEAR || d->P < 0 || d->F < 0 || d->n_opacity < 0)
+        return ggs_fail_(GGS_ERR_ARG, "ggs_step_prologue: bad sizes");
+    PrologueArgs a = {};
+    size_t work = 1;
+    for (int c = 0; c < d->n_clear; ++c) {
+        if (!d->clear_ptr[c] || (reinterpret_cast<uintptr_t>(d->clear_ptr[c]) & 3) || (d->clear_bytes[c] & 3))
+            return ggs_fail_(GGS_ERR_ARG, "ggs_step_prologue: clear range %d is NULL or not 4-byte aligned", c);
+        a.clr[c] = static_cast<uint32_t*>(d->clear_ptr[c]);
+        a.clr_words[c] = d->clear_bytes[c] / 4;
+        work = work > d->clear_bytes[c] / 16 ? work : d->clear_bytes[c] / 16;
+    }
+    a.n_clear = d->n_clear;
+    if (d->copy_bytes) {
+        if (!d->copy_src || !d->copy_dst || d->copy_bytes > 1024 || (d->copy_bytes & 3) ||
+            ((reinterpret_cast<uintptr_t>(d->copy_src) | reinterpret_cast<uintptr_t>(d->copy_dst)) & 3))
+            return ggs_fail_(GGS_ERR_ARG, "ggs_step_prologue: the block copy needs two 4-byte aligned pointers and <= 1024 bytes");
+        a.copy_src = static_cast<const uint32_t*>(d->copy_src); a.copy_dst = static_cast<uint32_t*>(d->copy_dst);
+        a.copy_words = (int)(d->copy_bytes / 4);
+    }
+    if (d->n_opacity) {
+        if (!d->opacity_logit || !d->opacity) return ggs_fail_(GGS_ERR_ARG, "ggs_step_prologue: NULL opacity pointer");
+        a.n_op = d->n_opacity; a.op_logit = d->opacity_logit; a.op = d->opacity;
+    }
+    if (d->P) {
+        if (!d->verts || !d->faces || !d->binding || !d->local_xyz || !d->log_scaling || !d->raw_rot || !d->xyz ||
+            !d->scaling || !d->rotation)
+            return ggs_fail_(GGS_ERR_ARG, "ggs_step_prologue: NULL mesh-binding pointer");
+        a.mesh.P = d->P; a.mesh.verts = d->verts; a.mesh.faces = d->faces; a.mesh.binding = d->binding;
+        a.mesh.local_xyz = d->local_xyz; a.mesh.log_scaling = d->log_scaling; a.mesh.raw_rot = d->raw_rot; a.mesh.bary = d->bary;
+        a.mesh.xyz = d->xyz; a.mesh.scaling = d->scaling; a.mesh.rotation = d->rotation;
+    }
+    size_t blocks = (work + 255) / 256;
+    blocks = blocks > 2048 ? 2048 : blocks;
+    const size_t per_item = ((size_t)(d->P > d->n_opacity ? d->P : d->n_opacity) + 255) / 256;
+    blocks = blocks > per_item ? blocks : per_item;
+    blocks = blocks < 1 ? 1 : blocks;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_step_prologue, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "step_prologue launch failed: %s", hipGetErrorString(e));
+    ggs_set_clear_marks_(d->n_clear, d->clear_ptr, d->clear_bytes, s);
     return GGS_OK;
 }
 

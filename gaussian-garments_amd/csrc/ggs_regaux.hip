@@ -24,6 +24,8 @@ struct RegArgs {
     float* out_losses;           // {loss_xyz, loss_scale, n_visible}
     float* sums;                 // scratch: {n_visible, sum hinge_xyz, sum hinge_scale}
     const unsigned long long* guard;
+    const float* tail_sums; const unsigned long long* tail_header; float* tail_out;     // GgsStepTail (tail_out NULL: none)
+    int n_adam; AdamState* adam[16]; double beta1, beta2;                                // GgsStepTail: optimiser states to advance
 };
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -58,10 +60,20 @@ __global__ __launch_bounds__(256) void k_reg_reduce(RegArgs a) {
 __global__ __launch_bounds__(256) void k_reg_apply(RegArgs a) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     const float n_vis = a.sums ? a.sums[0] : 0.f;
-    if (i == 0 && a.out_losses && a.sums) {
-        a.out_losses[0] = a.sums[1] / n_vis * a.lam_xyz;          // 0/0 = NaN like torch's mean over an empty selection
-        a.out_losses[1] = a.sums[2] / n_vis * a.lam_scale;
-        a.out_losses[2] = n_vis;
+    // optimiser states (GgsStepTail): thread t < n_adam of the first workgroup advances state t, like k_adam_tick_multi
+    if (blockIdx.x == 0 && (int)threadIdx.x < a.n_adam && !(a.guard && *a.guard))
+        ggs_adam_tick_one(a.adam[threadIdx.x], a.beta1, a.beta2);
+    if (i == 0) {
+        // 0/0 = NaN like torch's mean over an empty selection
+        const float lx = a.sums ? a.sums[1] / n_vis * a.lam_xyz : 0.f, ls = a.sums ? a.sums[2] / n_vis * a.lam_scale : 0.f;
+        if (a.out_losses && a.sums) { a.out_losses[0] = lx; a.out_losses[1] = ls; a.out_losses[2] = n_vis; }
+        if (a.tail_out) {                                          // the step's 48-byte result block (device or host-mapped)
+            float* o = a.tail_out;
+            o[0] = a.tail_sums ? a.tail_sums[0] : 0.f; o[1] = a.tail_sums ? a.tail_sums[1] : 0.f;
+            o[2] = lx; o[3] = ls; o[4] = n_vis; o[5] = o[6] = o[7] = 0.f;
+            unsigned long long* h = reinterpret_cast<unsigned long long*>(o + 8);
+            h[0] = a.tail_header ? a.tail_header[0] : 0ull; h[1] = a.tail_header ? a.tail_header[1] : 0ull;
+        }
     }
     if (i >= a.P) return;
     if (a.dL_dopacity_logit) {                                     // sigmoid backward
@@ -96,14 +108,20 @@ __global__ __launch_bounds__(256) void k_reg_apply(RegArgs a) {
 
 }  // namespace
 
-extern "C" int ggs_registration_aux(int P, const float* xyz, const float* log_scaling, const int* radii,
-                                    const float* dL_dmeans2D, const float* opacity, const float* dL_dopacity,
-                                    float* dL_dopacity_logit, float threshold_xyz, float lambda_xyz,
-                                    float threshold_scale, float lambda_scale, float* dL_dxyz, float* dL_dlog_scaling,
-                                    float* max_radii2D, float* xyz_gradient_accum, float* denom, float* out_losses,
-                                    void* scratch, const void* guard, void* stream) {
+extern "C" int ggs_registration_aux_tail(int P, const float* xyz, const float* log_scaling, const int* radii,
+                                         const float* dL_dmeans2D, const float* opacity, const float* dL_dopacity,
+                                         float* dL_dopacity_logit, float threshold_xyz, float lambda_xyz,
+                                         float threshold_scale, float lambda_scale, float* dL_dxyz, float* dL_dlog_scaling,
+                                         float* max_radii2D, float* xyz_gradient_accum, float* denom, float* out_losses,
+                                         void* scratch, const void* guard, const GgsStepTail* tail, void* stream) {
     ggs_clear_error_();
     if (P <= 0) return GGS_OK;
+    if (tail && (reinterpret_cast<uintptr_t>(tail->out_block) & 7))
+        return ggs_fail_(GGS_ERR_ARG, "ggs_registration_aux_tail: out_block is not 8-byte aligned");
+    if (tail && (tail->n_adam_states < 0 || tail->n_adam_states > 16))
+        return ggs_fail_(GGS_ERR_SIZE, "ggs_registration_aux_tail: at most 16 optimiser states");
+    for (int t = 0; tail && t < tail->n_adam_states; ++t)
+        if (!tail->adam_states[t]) return ggs_fail_(GGS_ERR_ARG, "ggs_registration_aux_tail: NULL optimiser state");
     if (!radii) return ggs_fail_(GGS_ERR_ARG, "ggs_registration_aux: radii is NULL");
     const bool hinge = dL_dxyz || dL_dlog_scaling;
     if (hinge && (!xyz || !log_scaling || !dL_dxyz || !dL_dlog_scaling || !scratch))
@@ -121,6 +139,11 @@ extern "C" int ggs_registration_aux(int P, const float* xyz, const float* log_sc
     a.max_radii2D = max_radii2D; a.xyz_gradient_accum = xyz_gradient_accum; a.denom = denom;
     a.out_losses = out_losses; a.sums = hinge ? static_cast<float*>(scratch) : nullptr;
     a.guard = static_cast<const unsigned long long*>(guard);
+    a.tail_sums = tail ? tail->loss_sums : nullptr;
+    a.tail_header = tail ? static_cast<const unsigned long long*>(tail->header) : nullptr;
+    a.tail_out = tail ? static_cast<float*>(tail->out_block) : nullptr;
+    a.n_adam = tail ? tail->n_adam_states : 0; a.beta1 = tail ? tail->beta1 : 0.0; a.beta2 = tail ? tail->beta2 : 0.0;
+    for (int t = 0; t < 16; ++t) a.adam[t] = t < a.n_adam ? static_cast<AdamState*>(tail->adam_states[t]) : nullptr;
     const dim3 grid((unsigned)((P + 255) / 256));
     if (hinge) {
         if (ggs_zero_async(scratch, 16, s) != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "ggs_registration_aux: clearing the sums failed");
@@ -130,4 +153,15 @@ extern "C" int ggs_registration_aux(int P, const float* xyz, const float* log_sc
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "registration_aux launch failed: %s", hipGetErrorString(e));
     return GGS_OK;
+}
+
+extern "C" int ggs_registration_aux(int P, const float* xyz, const float* log_scaling, const int* radii,
+                                    const float* dL_dmeans2D, const float* opacity, const float* dL_dopacity,
+                                    float* dL_dopacity_logit, float threshold_xyz, float lambda_xyz,
+                                    float threshold_scale, float lambda_scale, float* dL_dxyz, float* dL_dlog_scaling,
+                                    float* max_radii2D, float* xyz_gradient_accum, float* denom, float* out_losses,
+                                    void* scratch, const void* guard, void* stream) {
+    return ggs_registration_aux_tail(P, xyz, log_scaling, radii, dL_dmeans2D, opacity, dL_dopacity, dL_dopacity_logit,
+                                     threshold_xyz, lambda_xyz, threshold_scale, lambda_scale, dL_dxyz, dL_dlog_scaling,
+                                     max_radii2D, xyz_gradient_accum, denom, out_losses, scratch, guard, nullptr, stream);
 }

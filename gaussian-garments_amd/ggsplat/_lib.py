@@ -22,6 +22,22 @@ class GgsParams(C.Structure):
                 ("n_views", C.c_int), ("scale_modifier", C.c_float), ("prefiltered", C.c_int), ("debug", C.c_int)]
 
 
+class GgsStepPrologue(C.Structure):
+    """include/ggsplat.h GgsStepPrologue (ggs_step_prologue)."""
+    _fields_ = [("n_clear", C.c_int), ("clear_ptr", C.c_void_p * 8), ("clear_bytes", C.c_size_t * 8),
+                ("copy_src", C.c_void_p), ("copy_dst", C.c_void_p), ("copy_bytes", C.c_size_t),
+                ("P", C.c_int), ("F", C.c_int), ("verts", C.c_void_p), ("faces", C.c_void_p), ("binding", C.c_void_p),
+                ("local_xyz", C.c_void_p), ("log_scaling", C.c_void_p), ("raw_rot", C.c_void_p), ("bary", C.c_void_p),
+                ("xyz", C.c_void_p), ("scaling", C.c_void_p), ("rotation", C.c_void_p),
+                ("n_opacity", C.c_int), ("opacity_logit", C.c_void_p), ("opacity", C.c_void_p)]
+
+
+class GgsStepTail(C.Structure):
+    """include/ggsplat.h GgsStepTail (ggs_registration_aux_tail)."""
+    _fields_ = [("loss_sums", C.c_void_p), ("header", C.c_void_p), ("out_block", C.c_void_p),
+                ("n_adam_states", C.c_int), ("adam_states", C.c_void_p * 16), ("beta1", C.c_double), ("beta2", C.c_double)]
+
+
 class GgsError(RuntimeError):
     pass
 
@@ -61,7 +77,12 @@ _SIGS = {
     "ggs_adam_step": (C.c_int, [C.c_size_t, _PTR, _PTR, _PTR, _PTR, _PTR, C.c_double, C.c_double, C.c_double, _PTR, _PTR, _PTR]),
     "ggs_adam_tick_multi": (C.c_int, [C.c_int, _PTR, C.c_double, C.c_double, _PTR, _PTR]),
     "ggs_adam_step_multi": (C.c_int, [C.c_int] + [_PTR] * 7 + [C.c_double] * 3 + [_PTR] * 2),
+    "ggs_adam_tick_step_multi": (C.c_int, [C.c_int] + [_PTR] * 7 + [C.c_double] * 3 + [_PTR] * 2),
     "ggs_registration_aux": (C.c_int, [C.c_int] + [_PTR] * 7 + [C.c_float] * 4 + [_PTR] * 9),
+    "ggs_registration_aux_tail": (C.c_int, [C.c_int] + [_PTR] * 7 + [C.c_float] * 4 + [_PTR] * 8 + [C.POINTER(GgsStepTail), _PTR]),
+    "ggs_step_prologue": (C.c_int, [C.POINTER(GgsStepPrologue), _PTR]),
+    "ggs_step_clear_plan": (C.c_int, [C.POINTER(GgsParams), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
+    "ggs_host_mapped_pointer": (C.c_int, [_PTR, C.POINTER(C.c_void_p)]),
     "ggs_visibility_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_size_t]),
     "ggs_visibility": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 6 + [C.c_size_t, _PTR, _PTR, _PTR]),
     "ggs_count_blends": (C.c_int, [C.POINTER(GgsParams), _PTR, _PTR, C.c_size_t, _PTR, _PTR, _PTR]),
@@ -105,6 +126,14 @@ def ptr(t):
         return None
     assert t.is_contiguous(), "ggsplat: tensor must be contiguous"
     return t.data_ptr()             # ctypes converts the int for the void* parameters (no c_void_p object per argument)
+
+
+def host_mapped_pointer(t) -> int:
+    """Device address of a pinned host tensor (0 when the memory is not mapped into the device's address space)."""
+    out = C.c_void_p()
+    if not t.is_pinned() or lib().ggs_host_mapped_pointer(t.data_ptr(), C.byref(out)) != 0:
+        return 0
+    return int(out.value or 0)
 
 
 _SRC_ORDER = ("ggs_pergauss.hip", "ggs_binning.hip", "ggs_render.hip", "ggs_mesh.hip", "ggs_loss.hip", "ggs_knn.hip",

@@ -105,15 +105,22 @@ class GraphAdam:
                     else:
                         p.grad.zero_()
 
+    def tick_states(self, params=None) -> List[int]:
+        """Device addresses of the states step() would advance if every parameter of `params` (default: all) had a gradient --
+        for a caller that advances them itself (ggs_registration_aux_tail) and then calls step(tick=False)."""
+        ps = [p for g in self.param_groups for p in g["params"]] if params is None else list(params)
+        return [self.state[p]["state"].data_ptr() for p in ps if p.numel()]
+
     @torch.no_grad()
-    def step(self, guard: Optional[torch.Tensor] = None) -> None:
+    def step(self, guard: Optional[torch.Tensor] = None, tick: bool = True) -> None:
+        """tick=False: the step counts / bias corrections of the tensors that have a gradient were advanced already."""
         L = lib()
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         if guard is not None and (guard.element_size() != 8 or guard.device != self.device):
             raise ValueError("GraphAdam.step: guard must be a 64-bit word on the optimiser's device")
         gp = ptr(guard)
         b1, b2 = self.betas
-        # every tensor that has a gradient: one tick launch (step counts / bias corrections) and one update launch per 16
+        # every tensor that has a gradient: one launch per 16 tensors
         items = []
         for i, g in enumerate(self.param_groups):
             for p in g["params"]:
@@ -128,6 +135,7 @@ class GraphAdam:
             n = len(chunk)
             numel = (C.c_size_t * n)(*[c[0] for c in chunk])
             cols = [(C.c_void_p * n)(*[c[j] for c in chunk]) for j in range(1, 7)]
-            check(L.ggs_adam_tick_multi(n, cols[5], b1, b2, gp, stream), "ggs_adam_tick_multi")
-            check(L.ggs_adam_step_multi(n, numel, cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], b1, b2,
-                                        self.eps, gp, stream), "ggs_adam_step_multi")
+            # step counts / bias corrections advance inside the update launch (the last workgroup of a tensor stores them)
+            fn = L.ggs_adam_tick_step_multi if tick else L.ggs_adam_step_multi
+            check(fn(n, numel, cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], b1, b2, self.eps, gp, stream),
+                  "ggs_adam_tick_step_multi" if tick else "ggs_adam_step_multi")

@@ -228,6 +228,13 @@ class GraphedRegistrationStep:
         self._stats = self._out[:32].view(torch.float32)                  # {sum|x-y|, sum ssim, loss_xyz, loss_scale, n_vis}
         self._stats_host = self._out_host[:32].view(torch.float32)
         self._aux_scratch = torch.zeros(4, device=dev)
+        self._sums = torch.zeros(2, device=dev)                            # photometric sums of the step (lean form)
+        # Lean form: the parameter block is READ and the result block WRITTEN in place in pinned host memory by the step's
+        # first / last kernel (ggs_step_prologue, ggs_registration_aux_tail) when that memory is mapped into the device's
+        # address space -- no copy launch on either side of the replay.
+        from ._lib import host_mapped_pointer
+        self._blk_map = host_mapped_pointer(self._blk_host) if self.lean else 0
+        self._out_map = host_mapped_pointer(self._out_host) if self.lean else 0
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.out: Dict[str, torch.Tensor] = {}
         self.recaptures = 0
@@ -269,7 +276,8 @@ class GraphedRegistrationStep:
             m = self.mask if mask is None else self._resident(mask, self.mask, self.mask.shape)
         self._keep = (gt, m)
         self._host_p[0], self._host_p[1] = gt.data_ptr(), (m.data_ptr() if m is not None else 0)
-        self._blk.copy_(self._blk_host, non_blocking=True)
+        if not self._blk_map:
+            self._blk.copy_(self._blk_host, non_blocking=True)
         if not self.lean:           # the autograd form reads the images from the static buffers
             if gt is not self.gt:
                 self.gt.copy_(gt, non_blocking=True)
@@ -277,9 +285,11 @@ class GraphedRegistrationStep:
                 self.mask.copy_(m, non_blocking=True)
 
     def _body_lean(self, optimizer_step: bool, track: bool):
-        """registration_step() without autograd: the same kernels in the same order, called through the C ABI."""
+        """registration_step() without autograd: the same arithmetic in the same order, called through the C ABI.  14 launches:
+        prologue (zero fills | parameter block | sigmoid | mesh binding) -> forward (5) -> loss (2) -> backward (2) -> mesh
+        binding backward -> regularisers / statistics / result block (2) -> Adam."""
         import ctypes as C
-        from ._lib import check, lib, ptr
+        from ._lib import GgsStepPrologue, GgsStepTail, check, lib, ptr
         g, opt, cam = self.g, self.opt, self.cam
         L = lib()
         dev = g._xyz.device
@@ -289,16 +299,29 @@ class GraphedRegistrationStep:
         with torch.no_grad():
             verts, faces, binding, bary = g.mesh.v, g.mesh.f, g.binding, g.gs_bc
             xyz, scaling, rot = torch.empty_like(g._xyz), torch.empty_like(g._scaling), torch.empty_like(g._rotation)
-            check(L.ggs_mesh_bind_forward(P, Fn, ptr(verts), ptr(faces), ptr(binding), ptr(g._xyz), ptr(g._scaling),
-                                          ptr(g._rotation), ptr(bary), ptr(xyz), ptr(scaling), ptr(rot), stream),
-                  "ggs_mesh_bind_forward")
-            opacity = torch.sigmoid(g._opacity)
+            opacity = torch.empty_like(g._opacity)
+            d_verts = torch.empty_like(verts)
             K = 1 + g._features_rest.shape[1]
+            ws = R.plan_step(P, K, g.active_sh_degree, W, H, 1, dev)
+            pro = GgsStepPrologue()
+            clears = ((ws.bin, ws.bin_clear), (ws.scratch, ws.scratch_clear), (self._sums, 8), (self._aux_scratch, 16),
+                      (d_verts, d_verts.numel() * 4))
+            pro.n_clear = len(clears)
+            for i, (t, n) in enumerate(clears):
+                pro.clear_ptr[i], pro.clear_bytes[i] = t.data_ptr(), n
+            if self._blk_map:
+                pro.copy_src, pro.copy_dst, pro.copy_bytes = self._blk_map, self._blk.data_ptr(), 176
+            pro.P, pro.F = P, Fn
+            pro.verts, pro.faces, pro.binding = ptr(verts), ptr(faces), ptr(binding)
+            pro.local_xyz, pro.log_scaling, pro.raw_rot, pro.bary = ptr(g._xyz), ptr(g._scaling), ptr(g._rotation), ptr(bary)
+            pro.xyz, pro.scaling, pro.rotation = ptr(xyz), ptr(scaling), ptr(rot)
+            pro.n_opacity, pro.opacity_logit, pro.opacity = P, ptr(g._opacity), ptr(opacity)
+            check(L.ggs_step_prologue(C.byref(pro), stream), "ggs_step_prologue")
             shs = g._features_dc if K == 1 else torch.cat((g._features_dc, g._features_rest), dim=1)
             color, radii, _, _, st = R.forward_views(
                 xyz, opacity, shs, None, scaling, rot, None, view=cam.world_view_transform,
                 proj=cam.full_proj_transform, campos=cam.camera_center, tanfov=cam.tanfov, bg=self.bg, W=W, H=H,
-                sh_degree=g.active_sh_degree, debug=self.pipe.debug)
+                sh_degree=g.active_sh_degree, debug=self.pipe.debug, workspaces=ws)
             hdr = R.last_header()
             use_m = self.mask is not None and opt.only_foreground_loss
             gt_tab, m_tab = self._ptrs[0:1], (self._ptrs[1:2] if use_m else None)
@@ -306,12 +329,11 @@ class GraphedRegistrationStep:
             # region-of-interest form: dL/dimage only where the backward below reads it (tiles with a list: ~1 in 10 here)
             tc = R.last_tile_count()
             check(L.ggs_photometric_forward_roi(1, H, W, ptr(color), None, None, ptr(gt_tab), ptr(m_tab), ptr(tc),
-                                                ptr(self._stats[0:2]), ptr(scratch), stream), "ggs_photometric_forward_roi")
+                                                ptr(self._sums), ptr(scratch), stream), "ggs_photometric_forward_roi")
             dimg = torch.empty_like(color)
             check(L.ggs_photometric_backward_roi(1, H, W, ptr(color), None, None, ptr(gt_tab), ptr(m_tab), ptr(tc), ptr(scratch),
                                                  ptr(self._w), ptr(dimg), stream), "ggs_photometric_backward_roi")
-            gr = R.backward_views(st, dimg, want_means2D=True)
-            d_verts = torch.zeros_like(verts)
+            gr = R.backward_views(st, dimg, want_means2D=True, scratch=ws.scratch)
             d_xyz, d_ls, d_rr = torch.empty_like(g._xyz), torch.empty_like(g._scaling), torch.empty_like(g._rotation)
             check(L.ggs_mesh_bind_backward(P, Fn, ptr(verts), ptr(faces), ptr(binding), ptr(g._xyz), ptr(g._scaling),
                                            ptr(g._rotation), ptr(bary), ptr(gr["means3D"]), ptr(gr["scales"]),
@@ -319,19 +341,29 @@ class GraphedRegistrationStep:
                   "ggs_mesh_bind_backward")
             d_op = torch.empty_like(g._opacity)
             stats = self.fft and track
-            check(L.ggs_registration_aux(
+            # the result block {photometric sums, hinge losses, n_visible | bin header}: written by the last regulariser
+            # kernel, straight into the pinned host block when that is mapped (else into self._out, copied back by __call__)
+            tail = GgsStepTail(ptr(self._sums), ptr(hdr), self._out_map or self._out.data_ptr())
+            step_now = optimizer_step and g.optimizer is not None
+            if step_now:                    # ... and advances the optimiser states, so that the update is ONE launch
+                states = g.optimizer.tick_states()
+                tail.n_adam_states = len(states)
+                for i, a in enumerate(states):
+                    tail.adam_states[i] = a
+                tail.beta1, tail.beta2 = g.optimizer.betas
+            check(L.ggs_registration_aux_tail(
                 P, ptr(g._xyz), ptr(g._scaling), ptr(radii), ptr(gr["means2D"]), ptr(opacity), ptr(gr["opacities"]),
                 ptr(d_op), float(opt.threshold_xyz), float(opt.lambda_xyz), float(opt.threshold_scale),
                 float(opt.lambda_scale), ptr(d_xyz) if self.fft else None, ptr(d_ls) if self.fft else None,
                 ptr(g.max_radii2D) if stats else None, ptr(g.xyz_gradient_accum) if stats else None,
-                ptr(g.denom) if stats else None, ptr(self._stats[2:5]), ptr(self._aux_scratch), ptr(hdr[1:2]), stream),
-                "ggs_registration_aux")
-            if optimizer_step and g.optimizer is not None:
+                ptr(g.denom) if stats else None, None, ptr(self._aux_scratch), ptr(hdr[1:2]), C.byref(tail), stream),
+                "ggs_registration_aux_tail")
+            if step_now:
                 g.mesh.v.grad, g._xyz.grad, g._scaling.grad, g._rotation.grad, g._opacity.grad = d_verts, d_xyz, d_ls, d_rr, d_op
                 gs = gr["shs"]
                 g._features_dc.grad = gs if K == 1 else gs[:, :1].contiguous()
                 g._features_rest.grad = torch.empty_like(g._features_rest) if K == 1 else gs[:, 1:].contiguous()
-                g.optimizer.step(guard=hdr[1:2])
+                g.optimizer.step(guard=hdr[1:2], tick=False)
                 g.optimizer.zero_grad()
         return {}
 
@@ -376,7 +408,8 @@ class GraphedRegistrationStep:
             warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")   # capture stream
             out = self._body(optimizer_step=True, track=self.track)
             self._hdr_dev = R.last_header()
-            torch.add(self._hdr_dev, 0, out=self._out[32:48].view(torch.int64))   # next to the statistics: one read-back
+            if not self.lean:                    # (the lean form's last regulariser kernel assembles the whole block)
+                torch.add(self._hdr_dev, 0, out=self._out[32:48].view(torch.int64))   # next to the statistics: one read-back
         self.out = {k: v.detach() for k, v in out.items() if torch.is_tensor(v)}
         self._captured = self._identity()
 
@@ -399,7 +432,8 @@ class GraphedRegistrationStep:
             # the capture itself does not execute anything: fall through to the first replay
         while True:
             self.graph.replay()
-            self._out_host.copy_(self._out, non_blocking=True)
+            if not self._out_map:
+                self._out_host.copy_(self._out, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             self._keep = None
             if int(self._hdr_host[1]) == 0:

@@ -143,6 +143,28 @@ def _stream_ptr(dev) -> C.c_void_p:
     return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
 
 
+class StepWorkspaces:
+    """Workspaces of ONE forward + backward allocated up front (plan_step), so that a caller can name them -- and the two
+    ranges the library zero-fills first -- to ggs_step_prologue before the calls run."""
+    __slots__ = ("key", "cap", "geom", "img", "bin", "scratch", "bin_clear", "scratch_clear")
+
+
+def plan_step(P: int, K: int, sh_degree: int, W: int, H: int, V: int, dev) -> StepWorkspaces:
+    L = lib()
+    ws = StepWorkspaces()
+    ws.key = (dev.index, P, W, H, V)
+    ws.cap = cap = _cap_hint.get(ws.key, max(8 * P * V, 1 << 16))
+    prm = GgsParams(P, K, int(sh_degree), int(W), int(H), V, 1.0, 0, 0)
+    gsz, isz, bsz = _workspace_sizes(L, prm, cap)
+    new = (lambda n: torch.empty(n, device=dev, dtype=torch.uint8))
+    ws.geom, ws.img, ws.bin = new(gsz), new(isz), new(bsz)
+    ws.scratch = new(int(L.ggs_backward_scratch_bytes(C.byref(prm))))
+    a, b = C.c_size_t(), C.c_size_t()
+    check(L.ggs_step_clear_plan(C.byref(prm), cap, C.byref(a), C.byref(b)), "ggs_step_clear_plan")
+    ws.bin_clear, ws.scratch_clear = int(a.value), int(b.value)
+    return ws
+
+
 class ForwardState:
     """Everything the backward needs (the reference keeps the same things in ctx)."""
     __slots__ = ("prm", "bg", "means3D", "shs", "colors", "opac", "scales", "rots", "cov", "view", "proj",
@@ -151,9 +173,10 @@ class ForwardState:
 
 def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, *, view, proj, campos,
                   tanfov, bg, W: int, H: int, sh_degree: int, scale_modifier: float = 1.0, debug: bool = False,
-                  keep_state: bool = True):
+                  keep_state: bool = True, workspaces: Optional[StepWorkspaces] = None):
     """Rasterize V views.  view/proj [V,16], campos [V,3], tanfov [V,2], bg [V,3] or [3].
-    Returns color [V,3,H,W], radii [V,P] int32, depth [V,H,W], alpha [V,H,W], state."""
+    Returns color [V,3,H,W], radii [V,P] int32, depth [V,H,W], alpha [V,H,W], state.
+    workspaces: buffers from plan_step() for this shape (used as long as their capacity is the one the call runs with)."""
     L = lib()
     dev = means3D.device
     if dev.type != "cuda":
@@ -192,15 +215,19 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
     stream = C.c_void_p(cur_stream.cuda_stream)
     host = _pinned_header(dev)
     geom = img = None
+    ws = workspaces if (workspaces is not None and workspaces.key == key and workspaces.cap == cap) else None
     capturing = torch.cuda.is_current_stream_capturing()
     while capturing:        # one pass: static capacity, no host sync, overflow flag left on the device
         if key not in _cap_hint:
             raise _lib.GgsError("ggsplat: run this configuration eagerly once before capturing it into a graph "
                                 "(the binning capacity is learnt from an eager call)")
         gsz, isz, bsz = _workspace_sizes(L, prm, cap)
-        geom = torch.empty(gsz, device=dev, dtype=torch.uint8)
-        img = torch.empty(isz, device=dev, dtype=torch.uint8)
-        binb = torch.empty(bsz, device=dev, dtype=torch.uint8)
+        if ws is not None:
+            geom, img, binb = ws.geom, ws.img, ws.bin
+        else:
+            geom = torch.empty(gsz, device=dev, dtype=torch.uint8)
+            img = torch.empty(isz, device=dev, dtype=torch.uint8)
+            binb = torch.empty(bsz, device=dev, dtype=torch.uint8)
         args = (C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales),
                 ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov), ptr(geom),
                 ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha), ptr(radii), stream)
@@ -209,11 +236,14 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
         break
     while not capturing:
         gsz, isz, bsz = _workspace_sizes(L, prm, cap)
-        if geom is None:
-            geom = torch.empty(gsz, device=dev, dtype=torch.uint8)
-        if img is None or img.numel() < isz:
-            img = torch.empty(isz, device=dev, dtype=torch.uint8)
-        binb = torch.empty(bsz, device=dev, dtype=torch.uint8)
+        if ws is not None and ws.cap == cap:          # (an overflow retry runs with a larger capacity and its own buffers)
+            geom, img, binb = ws.geom, ws.img, ws.bin
+        else:
+            if geom is None:
+                geom = torch.empty(gsz, device=dev, dtype=torch.uint8)
+            if img is None or img.numel() < isz:
+                img = torch.empty(isz, device=dev, dtype=torch.uint8)
+            binb = torch.empty(bsz, device=dev, dtype=torch.uint8)
         args = (C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales),
                 ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov), ptr(geom),
                 ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha), ptr(radii), stream)
@@ -247,8 +277,9 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
 
 
 def backward_views(st: ForwardState, dL_dcolor, dL_ddepth=None, dL_dalpha=None, want_means2D: bool = True,
-                   out: Optional[Dict[str, torch.Tensor]] = None, accumulate: bool = False) -> Dict[str, torch.Tensor]:
-    """Gradients summed over the V views of `st` (dL_dmeans2D stays per view)."""
+                   out: Optional[Dict[str, torch.Tensor]] = None, accumulate: bool = False,
+                   scratch: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+    """Gradients summed over the V views of `st` (dL_dmeans2D stays per view).  scratch: plan_step().scratch or None."""
     L = lib()
     prm = st.prm
     dev = st.means3D.device
@@ -277,7 +308,8 @@ def backward_views(st: ForwardState, dL_dcolor, dL_ddepth=None, dL_dalpha=None, 
         if len(_bwd_scratch) > 256:
             _bwd_scratch.clear()
         nbytes = _bwd_scratch[k] = int(L.ggs_backward_scratch_bytes(C.byref(prm)))
-    scratch = torch.empty(nbytes, device=dev, dtype=torch.uint8)
+    if scratch is None or scratch.numel() < nbytes:
+        scratch = torch.empty(nbytes, device=dev, dtype=torch.uint8)
     check(L.ggs_backward(C.byref(prm), ptr(st.bg), ptr(st.means3D), ptr(st.shs), ptr(st.colors), ptr(st.scales),
                          ptr(st.rots), ptr(st.cov), ptr(st.view), ptr(st.proj), ptr(st.campos), ptr(st.tanfov),
                          ptr(st.geom), ptr(st.bin), st.cap, ptr(st.img), ptr(dL_dcolor), ptr(dL_ddepth),

@@ -290,6 +290,13 @@ int ggs_adam_step_multi(int n_tensors, const size_t* numel, float* const* params
                         float* const* exp_avgs, float* const* exp_avg_sqs, const float* const* lrs,
                         const void* const* states, double beta1, double beta2, double eps, const void* guard,
                         void* stream);
+/* ggs_adam_tick_multi + ggs_adam_step_multi in ONE launch (one launch less per optimisation step: ~5 us of a graph-replayed
+ * iteration).  Every tensor is listed once; its state is advanced once.  The last 8 bytes of a state are a workgroup ticket
+ * that is zero whenever no launch is in flight; a checkpoint keeps the first 32 bytes. */
+int ggs_adam_tick_step_multi(int n_tensors, const size_t* numel, float* const* params, const float* const* grads,
+                             float* const* exp_avgs, float* const* exp_avg_sqs, const float* const* lrs,
+                             void* const* states, double beta1, double beta2, double eps, const void* guard,
+                             void* stream);
 
 /*
  * The rest of one s2 registration iteration in two kernels: hinge regularisers of the first-frame
@@ -307,6 +314,60 @@ int ggs_registration_aux(int P, const float* xyz, const float* log_scaling, cons
                          float lambda_xyz, float threshold_scale, float lambda_scale, float* dL_dxyz,
                          float* dL_dlog_scaling, float* max_radii2D, float* xyz_gradient_accum, float* denom,
                          float* out_losses, void* scratch, const void* guard, void* stream);
+/* The same, and thread 0 of its last kernel also advances the optimiser states (ggs_adam_tick_multi) and assembles the step's
+ * 48-byte result block -- what a graph-replayed step otherwise does with two small kernels and a copy launch (~5 us each):
+ *   out_block: float[8] {sum|x - y|, sum ssim_map, loss_xyz, loss_scale, n_visible, 0, 0, 0} | u64[2] GgsBinHeader.
+ * out_block may be host-mapped page-locked memory (ggs_host_mapped_pointer): the host then reads the block after synchronising
+ * with the stream, without any copy.  loss_sums / header may be NULL (zeros are stored). */
+typedef struct GgsStepTail {
+    const float* loss_sums;     /* [2] device: the sums ggs_photometric_forward* produced in this step */
+    const void* header;         /* device: GgsBinHeader of this step's forward (the first 16 bytes of `bin`) */
+    void* out_block;            /* 48 bytes, 8-byte aligned; NULL: no result block */
+    /* ggs_adam_tick_multi's arguments (n_adam_states = 0: none): the optimiser states are advanced here, under `guard`, so
+     * that the update that follows is one ggs_adam_step_multi launch and nothing else */
+    int n_adam_states;          /* <= 16 */
+    void* adam_states[16];
+    double beta1, beta2;
+} GgsStepTail;
+int ggs_registration_aux_tail(int P, const float* xyz, const float* log_scaling, const int* radii, const float* dL_dmeans2D,
+                              const float* opacity, const float* dL_dopacity, float* dL_dopacity_logit, float threshold_xyz,
+                              float lambda_xyz, float threshold_scale, float lambda_scale, float* dL_dxyz,
+                              float* dL_dlog_scaling, float* max_radii2D, float* xyz_gradient_accum, float* denom,
+                              float* out_losses, void* scratch, const void* guard, const GgsStepTail* tail, void* stream);
+
+/*
+ * Step prologue: the jobs at the head of one optimisation step that depend on nothing computed in it, as ONE launch.  Inside a
+ * captured hipGraph a dependent launch costs ~5 us whatever it does; the s2 iteration had eight such launches (four zero fills,
+ * the 176-byte parameter copy, sigmoid, a gradient fill, the mesh binding) in front of ~400 us of real work.
+ *   clear_ptr / clear_bytes [n_clear <= 8]: ranges to zero-fill (4-byte aligned).  Every range is then MARKED for the calling
+ *     host thread and `stream`: the next library call on that thread and stream that would itself zero-fill a range starting
+ *     at the same address and no longer -- the binning counters of ggs_forward* (ggs_step_clear_plan: bin_bytes at `bin`), the
+ *     gradient records of ggs_backward (backward_scratch_bytes at `scratch`), the sums of ggs_photometric_forward* (8 n_views
+ *     bytes), the 16-byte scratch of ggs_registration_aux -- consumes the mark and skips its own fill launch.  Marks nobody
+ *     consumed are dropped by the next ggs_step_prologue of the thread.  The caller must not write to a marked range before its
+ *     consumer ran.  Ranges without a consumer are simply zero-filled (e.g. dL_dverts of ggs_mesh_bind_backward).
+ *   copy_src -> copy_dst, copy_bytes <= 1024 (4-byte aligned; 0: none): a small block copy; copy_src may be host-mapped
+ *     page-locked memory, read in place (the per-iteration camera / pointer block without a copy launch).
+ *   P, F, verts ... rotation: the arguments of ggs_mesh_bind_forward (P = 0: no binding).
+ *   opacity[i] = 1 / (1 + exp(-opacity_logit[i])), i < n_opacity (scene/gaussian_model.py:107-108; 0: none).
+ */
+#define GGS_PROLOGUE_MAX_CLEAR 8
+typedef struct GgsStepPrologue {
+    int n_clear;
+    void* clear_ptr[GGS_PROLOGUE_MAX_CLEAR];
+    size_t clear_bytes[GGS_PROLOGUE_MAX_CLEAR];
+    const void* copy_src; void* copy_dst; size_t copy_bytes;
+    int P, F;
+    const float* verts; const int64_t* faces; const int64_t* binding;
+    const float *local_xyz, *log_scaling, *raw_rot, *bary;
+    float *xyz, *scaling, *rotation;
+    int n_opacity; const float* opacity_logit; float* opacity;
+} GgsStepPrologue;
+int ggs_step_prologue(const GgsStepPrologue* d, void* stream);
+/* Leading bytes of `bin` that ggs_forward* and of `scratch` that ggs_backward zero-fill first. */
+int ggs_step_clear_plan(const GgsParams* p, size_t bin_capacity, size_t* bin_bytes, size_t* backward_scratch_bytes);
+/* Device address of mapped page-locked host memory (hipHostMalloc: PyTorch's pinned tensors); GGS_ERR_HIP if it is not. */
+int ggs_host_mapped_pointer(void* host_ptr, void** device_ptr);
 
 /*
  * Visibility of mesh-bound Gaussians from one camera -- replaces the per-iteration open3d / Embree

@@ -3,7 +3,7 @@
 # Run through gpurun from the repo root:  gpurun --timeout 900 -- 'bash tools/dbg/job.sh ubench_lds census ab'
 # Every step writes under gpurun_out/ (merged back by gpurun).  Environment: TAG (file-name prefix, default r04),
 # TESTS (pytest selection for `partests`), LIBS (variant names for `ab` / `partests`, default: all of csrc/variants/*.so),
-# BENCH_ARGS (extra bench.py flags for `ab`).
+# BENCH_ARGS (extra bench.py flags for `ab`).  seltests: TESTS = the selection.
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
 export TMPDIR=/tmp
 TAG=${TAG:-r04}
@@ -30,6 +30,16 @@ import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_
       for f in $(libs); do n=$(basename $f .so); GGS_LIB_PATH=$PWD/$f PASSES="${PASSES:-sq lds}" bash tools/profile_all.sh ${TAG}_$n $PROF_ARGS > $OUT/${TAG}_prof_$n.log 2>&1
         cat $OUT/prof_${TAG}_${n}_sq_counters.md $OUT/prof_${TAG}_${n}_lds_counters.md 2>/dev/null | grep -v "^$"; done ;;
     gputests)        timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 > $OUT/${TAG}_gputests.txt; cat $OUT/${TAG}_gputests.txt ;;
+    seltests)        # a pytest selection (TESTS) against the product library
+      timeout 2400 python -m pytest ${TESTS:-tests/test_gpu_graph_step.py} -x -q 2>&1 | tail -25 > $OUT/${TAG}_seltests.txt; cat $OUT/${TAG}_seltests.txt ;;
+    graphstep)       # graph-replayed s2 iteration: it/s, three interleaved runs of the product library or of the variants in LIBS
+      for i in 1 2 3; do for f in $( [ -z "$LIBS" ] && echo gaussian-garments_amd/csrc/libggsplat.so || libs ); do echo -n "$(basename $f): "; GGS_LIB_PATH=$PWD/$f timeout 600 python tools/profile_graph_step.py 256 2>&1 | tail -1; done; done > $OUT/${TAG}_graphstep.txt; cat $OUT/${TAG}_graphstep.txt ;;
+    graphprof)       # kernel table of the graph-replayed s2 iteration (rocprofv3 --kernel-trace, last 60 periods)
+      R=$PWD; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/gs -o g -- python $R/tools/profile_graph_step.py 64 > $R/$OUT/gs.log 2>&1)
+      python tools/rocpd_summary.py $(find $OUT/gs -name "*.db" | head -1) --cycles 60 --anchor ${ANCHOR:-k_adam_multi} > $OUT/${TAG}_graph_step_kernels.md 2>&1
+      grep "graphed s2 step" $OUT/gs.log >> $OUT/${TAG}_graph_step_kernels.md; rm -rf $OUT/gs; cat $OUT/${TAG}_graph_step_kernels.md ;;
+    timeloss)        # fused photometric loss, us per 1080p view, for each variant library (LIBS) or the product (LIBS=product)
+      for f in $( [ "$LIBS" = product ] && echo gaussian-garments_amd/csrc/libggsplat.so || libs ); do echo "--- $f"; for i in 1 2; do GGS_LIB_PATH=$PWD/$f timeout 300 python tools/dbg/time_loss.py 2>&1 | grep "^V="; done; done > $OUT/${TAG}_timeloss.txt; cat $OUT/${TAG}_timeloss.txt ;;
     bench)           timeout 900 python bench.py $BENCH_ARGS > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; cat $OUT/${TAG}_bench.json ;;
     *) echo "unknown step $step" ;;
   esac
