@@ -40,6 +40,7 @@ import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_
       grep "graphed s2 step" $OUT/gs.log >> $OUT/${TAG}_graph_step_kernels.md; rm -rf $OUT/gs; cat $OUT/${TAG}_graph_step_kernels.md ;;
     timeloss)        # fused photometric loss, us per 1080p view, for each variant library (LIBS) or the product (LIBS=product)
       for f in $( [ "$LIBS" = product ] && echo gaussian-garments_amd/csrc/libggsplat.so || libs ); do echo "--- $f"; for i in 1 2; do GGS_LIB_PATH=$PWD/$f timeout 300 python tools/dbg/time_loss.py 2>&1 | grep "^V="; done; done > $OUT/${TAG}_timeloss.txt; cat $OUT/${TAG}_timeloss.txt ;;
+    autograd_floor)  timeout 300 python tools/dbg/autograd_floor.py > $OUT/${TAG}_autograd_floor.txt 2>&1; cat $OUT/${TAG}_autograd_floor.txt ;;
     bench)           timeout 900 python bench.py $BENCH_ARGS > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; cat $OUT/${TAG}_bench.json ;;
     *) echo "unknown step $step" ;;
   esac
