@@ -64,13 +64,16 @@ __device__ __forceinline__ bool any_tile(const LossArgs& a, int v, int x0, int y
     return __builtin_amdgcn_ballot_w64(hit) != 0;
 }
 
+template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* s_red) {
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane == 0) s_red[wave] = v;
     __syncthreads();
-    v = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += s_red[w];
     __syncthreads();
     return v;
 }
@@ -105,6 +108,12 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
 #ifndef GGS_LOSS_SPLIT_READS                         // 1: at most 22 LDS values in flight (what 128 VGPRs hold without spilling more)
 #define GGS_LOSS_SPLIT_READS (GGS_LOSS_WAVES >= 4)
 #endif
+// Pass A comes in two workgroup shapes.  NCH = 3: a workgroup holds the three colour channels of its four bands (12 waves = one
+// CU's worth at 3 waves per SIMD): 240 workgroups per view instead of 720 end in the two same-address atomics of the sums -- those
+// retire one every ~10 ns, and when all workgroups of a view finish together that tail is 7.5 of the kernel's 48 us (one view:
+// 54 -> 50 us, 48 -> 43 inside the captured step).  NCH = 1 (four waves, one channel) for launches of several views, whose
+// workgroups finish spread out and want the finer scheduling grain (16 views: 50.6 against 52.4 us per view).
+#define LS_CH3_MAX_VIEWS 2
 #define LS_COLS 64
 #define LS_HB 34                          // LS_HB + 2 LH = 44 input rows = 4 x 11.  (12-row bands for single-view launches --
                                           // 2.8x the waves, half the dependent row steps each, 1.8x the filtered rows --
@@ -270,11 +279,11 @@ struct StatsStep {
     template <int R> static __device__ __forceinline__ void run(StatsCtx& c, RowRing<4>& r, int i) { stats_step<R, MASK>(c, r, i); }
 };
 
-template <bool MASK>
+template <bool MASK, int NCH>
 __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float (*s_x)[4][2][LS_IN], float* s_red) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-    const int v = blockIdx.z / 3, ch = blockIdx.z % 3;
-    const int band = blockIdx.y * LS_WAVES + wave;
+    const int v = NCH == 3 ? blockIdx.z : blockIdx.z / 3, ch = NCH == 3 ? wave / LS_WAVES : blockIdx.z % 3;
+    const int band = blockIdx.y * LS_WAVES + wave % LS_WAVES;
     const size_t HW = (size_t)a.H * a.W;
     StatsCtx c;
     c.img = a.img + ((size_t)v * 3 + ch) * HW;
@@ -303,7 +312,7 @@ __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float 
             st_off(c.dm, p, c.o0); st_off(c.dm1, p, c.o1); st_off(c.dm2, p, c.o2);
         }
     }
-    const float l1 = block_sum(c.l1, s_red), ssum = block_sum(c.ssum, s_red);
+    const float l1 = block_sum<NCH * LS_WAVES>(c.l1, s_red), ssum = block_sum<NCH * LS_WAVES>(c.ssum, s_red);
     if (threadIdx.x == 0) {
         atomicAdd(&a.sums[2 * v], l1);
         atomicAdd(&a.sums[2 * v + 1], ssum);
@@ -312,19 +321,19 @@ __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float 
 
 }  // namespace
 
-// Pass A: grid (ceil(W/64), ceil(ceil(H/34)/4), V*3), block 256 = 4 independent waves.
+// Pass A: grid (ceil(W/64), ceil(ceil(H/34)/4), V * 3 / NCH), block 256 NCH = 4 NCH independent waves.
 // (Masked and unmasked forms are separate kernels: as two branches of one kernel the register allocation of the shared
 // prologue pushed the masked body over its register budget.)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GGS_LOSS_WAVES, GGS_LOSS_WAVES))) void ggs_k_loss_stats(LossArgs a) {
-    __shared__ float s_x[LS_WAVES][4][2][LS_IN];
-    __shared__ float s_red[4];
-    loss_stats_stream_body<false>(a, s_x, s_red);
-}
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(GGS_LOSS_WAVES, GGS_LOSS_WAVES))) void ggs_k_loss_stats_masked(LossArgs a) {
-    __shared__ float s_x[LS_WAVES][4][2][LS_IN];
-    __shared__ float s_red[4];
-    loss_stats_stream_body<true>(a, s_x, s_red);
-}
+#define GGS_LOSS_STATS_KERNEL(NAME, MASK, NCH)                                                                              \
+    __global__ __launch_bounds__(256 * NCH) __attribute__((amdgpu_waves_per_eu(GGS_LOSS_WAVES, GGS_LOSS_WAVES))) void NAME(LossArgs a) { \
+        __shared__ float s_x[LS_WAVES * NCH][4][2][LS_IN];                                                                  \
+        __shared__ float s_red[LS_WAVES * NCH];                                                                             \
+        loss_stats_stream_body<MASK, NCH>(a, s_x, s_red);                                                                   \
+    }
+GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats, false, 1)
+GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats_masked, true, 1)
+GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats_ch3, false, 3)
+GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats_masked_ch3, true, 3)
 
 namespace {
 
@@ -479,8 +488,13 @@ static int photometric_forward(int n_views, int H, int W, const float* img, cons
     if (ggs_zero_async(sums, (size_t)n_views * 2 * sizeof(float), s) != hipSuccess)
         return ggs_fail_(GGS_ERR_HIP, "ggs_photometric_forward: clearing the sums failed");
     const int bands = (H + LS_HB - 1) / LS_HB;
-    const dim3 grid((unsigned)((W + LS_COLS - 1) / LS_COLS), (unsigned)((bands + LS_WAVES - 1) / LS_WAVES), (unsigned)(n_views * 3));
-    if (a.mask || a.mask_tab) hipLaunchKernelGGL(ggs_k_loss_stats_masked, grid, dim3(256), 0, s, a);
+    const bool ch3 = n_views <= LS_CH3_MAX_VIEWS;
+    const dim3 grid((unsigned)((W + LS_COLS - 1) / LS_COLS), (unsigned)((bands + LS_WAVES - 1) / LS_WAVES),
+                    (unsigned)(ch3 ? n_views : n_views * 3));
+    const bool masked = a.mask || a.mask_tab;
+    if (ch3 && masked) hipLaunchKernelGGL(ggs_k_loss_stats_masked_ch3, grid, dim3(768), 0, s, a);
+    else if (ch3) hipLaunchKernelGGL(ggs_k_loss_stats_ch3, grid, dim3(768), 0, s, a);
+    else if (masked) hipLaunchKernelGGL(ggs_k_loss_stats_masked, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(ggs_k_loss_stats, grid, dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "loss_stats launch failed: %s", hipGetErrorString(e));

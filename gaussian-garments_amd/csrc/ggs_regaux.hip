@@ -34,18 +34,28 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Grid-stride over at most REG_REDUCE_BLOCKS workgroups: the three sums end in one atomic each per workgroup on the SAME cache
+// line, and same-address atomics retire one every ~10 ns -- with one workgroup per 256 Gaussians (391 x 3 at 100k) that tail was
+// most of this kernel's 7 us.
+#define REG_REDUCE_BLOCKS 128
 __global__ __launch_bounds__(256) void k_reg_reduce(RegArgs a) {
     __shared__ float red[3][4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
     float n = 0.f, hx = 0.f, hs = 0.f;
-    if (i < a.P && a.radii[i] > 0) {
-        n = 1.f;
-        const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
-        hx = fmaxf(sqrtf(x * x + y * y + z * z) - a.thr_xyz, 0.f);
-        const float s0 = fmaxf(expf(a.log_scaling[3 * i]) - a.thr_scale, 0.f);
-        const float s1 = fmaxf(expf(a.log_scaling[3 * i + 1]) - a.thr_scale, 0.f);
-        const float s2 = fmaxf(expf(a.log_scaling[3 * i + 2]) - a.thr_scale, 0.f);
-        hs = sqrtf(s0 * s0 + s1 * s1 + s2 * s2);
+    const int stride = gridDim.x * 256;
+    // branch-free body on clamped indices, four Gaussians per thread in flight: the loads of a thread do not wait for each other
+    for (int i0 = blockIdx.x * 256 + threadIdx.x; i0 < a.P; i0 += 4 * stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = i0 + u * stride, i = j < a.P ? j : a.P - 1;
+            const bool vis = j < a.P && a.radii[i] > 0;
+            const float x = a.xyz[3 * i], y = a.xyz[3 * i + 1], z = a.xyz[3 * i + 2];
+            const float s0 = fmaxf(expf(a.log_scaling[3 * i]) - a.thr_scale, 0.f);
+            const float s1 = fmaxf(expf(a.log_scaling[3 * i + 1]) - a.thr_scale, 0.f);
+            const float s2 = fmaxf(expf(a.log_scaling[3 * i + 2]) - a.thr_scale, 0.f);
+            n += vis ? 1.f : 0.f;                                            // selects, not products: an invisible Gaussian may hold inf
+            hx += vis ? fmaxf(sqrtf(x * x + y * y + z * z) - a.thr_xyz, 0.f) : 0.f;
+            hs += vis ? sqrtf(s0 * s0 + s1 * s1 + s2 * s2) : 0.f;
+        }
     }
     n = wave_sum(n); hx = wave_sum(hx); hs = wave_sum(hs);
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -147,7 +157,8 @@ extern "C" int ggs_registration_aux_tail(int P, const float* xyz, const float* l
     const dim3 grid((unsigned)((P + 255) / 256));
     if (hinge) {
         if (ggs_zero_async(scratch, 16, s) != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "ggs_registration_aux: clearing the sums failed");
-        hipLaunchKernelGGL(k_reg_reduce, grid, dim3(256), 0, s, a);
+        const dim3 grid_r(grid.x < REG_REDUCE_BLOCKS ? grid.x : REG_REDUCE_BLOCKS);
+        hipLaunchKernelGGL(k_reg_reduce, grid_r, dim3(256), 0, s, a);
     }
     hipLaunchKernelGGL(k_reg_apply, grid, dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
