@@ -128,6 +128,18 @@ def ptr(t):
     return t.data_ptr()             # ctypes converts the int for the void* parameters (no c_void_p object per argument)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
+def stream_ptr(dev) -> int:
+    """HIP stream handle of PyTorch's current stream on `dev`, as an int (ctypes converts it for the void* parameters).
+    torch.cuda.current_stream() builds a Python Stream object per call (~5 us, six calls per eager s2 step)."""
+    if _raw_stream is not None:
+        i = dev.index
+        return _raw_stream(torch.cuda.current_device() if i is None else i)
+    return torch.cuda.current_stream(dev).cuda_stream
+
+
 def host_mapped_pointer(t) -> int:
     """Device address of a pinned host tensor (0 when the memory is not mapped into the device's address space)."""
     out = C.c_void_p()

@@ -17,7 +17,7 @@ from typing import Dict, Iterable, List, Optional
 
 import torch
 
-from ._lib import check, lib, ptr
+from ._lib import check, lib, ptr, stream_ptr
 
 
 class GraphAdam:
@@ -115,7 +115,7 @@ class GraphAdam:
     def step(self, guard: Optional[torch.Tensor] = None, tick: bool = True) -> None:
         """tick=False: the step counts / bias corrections of the tensors that have a gradient were advanced already."""
         L = lib()
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        stream = stream_ptr(self.device)
         if guard is not None and (guard.element_size() != 8 or guard.device != self.device):
             raise ValueError("GraphAdam.step: guard must be a 64-bit word on the optimiser's device")
         gp = ptr(guard)

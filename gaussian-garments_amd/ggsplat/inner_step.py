@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from . import rasterizer as R
 from .adam import GraphAdam
 from .loss import fused_photometric_loss, l1_loss, ssim
+from ._lib import stream_ptr
 from .render import render
 
 DEFAULT_OPT = SimpleNamespace(                      # arguments/__init__.py:74-116 (the values the steps read)
@@ -62,7 +63,7 @@ class _HingeRegularisers(torch.autograd.Function):
         r = radii if (radii.dtype is torch.int32 and radii.is_contiguous()) else radii.to(torch.int32).contiguous()
         check(lib().ggs_registration_aux(P, ptr(x), ptr(ls), ptr(r), None, None, None, None, float(thr_xyz), float(lam_xyz),
                                          float(thr_scale), float(lam_scale), ptr(d_xyz), ptr(d_ls), None, None, None, ptr(out),
-                                         ptr(scratch), None, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                                         ptr(scratch), None, stream_ptr(dev)),
               "ggs_registration_aux")
         ctx.saved = (d_xyz, d_ls)
         ctx.mark_non_differentiable(radii)
@@ -85,7 +86,7 @@ def _densification_stats_fused(gaussians, vsp_grad, radii, hdr):
     gr = vsp_grad if vsp_grad.is_contiguous() else vsp_grad.contiguous()
     check(lib().ggs_registration_aux(g._xyz.shape[0], None, None, ptr(r), ptr(gr), None, None, None, 0.0, 0.0, 0.0, 0.0, None, None,
                                      ptr(g.max_radii2D), ptr(g.xyz_gradient_accum), ptr(g.denom), None, None,
-                                     None if hdr is None else ptr(hdr[1:2]), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                                     None if hdr is None else ptr(hdr[1:2]), stream_ptr(dev)),
           "ggs_registration_aux")
 
 
@@ -293,7 +294,7 @@ class GraphedRegistrationStep:
         g, opt, cam = self.g, self.opt, self.cam
         L = lib()
         dev = g._xyz.device
-        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        stream = stream_ptr(dev)
         H, W = cam.image_height, cam.image_width
         P, Fn = g._xyz.shape[0], g.mesh.f.shape[0]
         with torch.no_grad():

@@ -74,7 +74,7 @@ class _FusedPhotometric(torch.autograd.Function):
     @staticmethod
     def forward(ctx, image, gt, mask, lambda_dssim, tile_count=None):
         import ctypes as C
-        from ._lib import check, lib, ptr
+        from ._lib import check, lib, ptr, stream_ptr
         if image.device.type != "cuda":
             raise RuntimeError("ggsplat fused loss runs on the GPU only (no CPU path in the product)")
         img, g = _f32c4(image), _f32c4(gt)
@@ -96,7 +96,7 @@ class _FusedPhotometric(torch.autograd.Function):
             if tc.dtype not in (torch.int32, torch.uint32) or tc.numel() != V * ((H + 15) // 16) * ((W + 15) // 16):
                 raise ValueError("fused_photometric_loss: tile_count must be int32 [V, ceil(H/16) * ceil(W/16)]")
         check(L.ggs_photometric_forward_roi(V, H, W, ptr(img), ptr(g), ptr(m), None, None, ptr(tc), ptr(sums), ptr(scratch),
-                                            C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                                            stream_ptr(dev)),
               "ggs_photometric_forward")
         lam = float(lambda_dssim)
         scale, bias, _ = _consts(dev, lam, 3.0 * H * W)
@@ -111,7 +111,7 @@ class _FusedPhotometric(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_img, g_ssim):
         import ctypes as C
-        from ._lib import check, lib, ptr
+        from ._lib import check, lib, ptr, stream_ptr
         img, g, m, scratch, lam, in_shape, tc, src, ver = ctx.saved
         if src is not None and src._version != ver:
             raise RuntimeError("one of the variables needed for gradient computation has been modified by an inplace operation: "
@@ -128,7 +128,7 @@ class _FusedPhotometric(torch.autograd.Function):
         # that a gradient summed with other consumers of the image stays finite
         dimg = torch.empty_like(img) if tc is None else torch.zeros_like(img)
         check(lib().ggs_photometric_backward_roi(V, H, W, ptr(img), ptr(g), ptr(m), None, None, ptr(tc), ptr(scratch), ptr(w),
-                                                 ptr(dimg), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)),
+                                                 ptr(dimg), stream_ptr(dev)),
               "ggs_photometric_backward")
         return dimg.reshape(in_shape), None, None, None, None
 

@@ -28,12 +28,12 @@ from types import SimpleNamespace
 import torch
 from torch import nn
 
-from ._lib import check, lib, ptr
+from ._lib import check, lib, ptr, stream_ptr
 from .densify import DensifyMixin
 
 
 def _stream(dev):
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    return stream_ptr(dev)
 
 
 def _f32c(t):

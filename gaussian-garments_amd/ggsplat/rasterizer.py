@@ -139,8 +139,8 @@ def tanfov_tensor(tanfovx: float, tanfovy: float, dev) -> torch.Tensor:
     return t
 
 
-def _stream_ptr(dev) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+def _stream_ptr(dev) -> int:
+    return _lib.stream_ptr(dev)
 
 
 class StepWorkspaces:
@@ -211,8 +211,7 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
 
     key = (dev.index, P, W, H, V)
     cap = _cap_hint.get(key, max(8 * P * V, 1 << 16))
-    cur_stream = torch.cuda.current_stream(dev)
-    stream = C.c_void_p(cur_stream.cuda_stream)
+    stream = _lib.stream_ptr(dev)
     host = _pinned_header(dev)
     geom = img = None
     ws = workspaces if (workspaces is not None and workspaces.key == key and workspaces.cap == cap) else None
