@@ -245,7 +245,7 @@ def test_s2_form_full_size_against_the_oracle_pipeline(skirt):
     assert np.array_equal(pkg["radii"].cpu().numpy(), co.radii)
     assert rel_l1(pkg["render"], co.color) <= REL_L1_TOL
     for k, r in (("img", l_img), ("ssim", l_ssim), ("xyz", l_xyz), ("scale", l_sc)):
-        assert abs(float(out[k]) - float(r)) <= 2e-5 * max(1.0, abs(float(r))), k
+        assert abs(float(out[k].detach()) - float(r.detach())) <= 2e-5 * max(1.0, abs(float(r.detach()))), k
     names = [n for n in NAMES if leaf[n].numel()] + ["mesh.v"]
     gpu = [getattr(model, n).grad for n in names[:-1]] + [model.mesh.v.grad]
     _report_and_bound("s2 form, 100k / 1080p", names, gpu, leaves, scale, e2e)

@@ -20,7 +20,7 @@ def _ref(img, gt, mask, lam, wa=1.0, wb=1.0):
     l_img = HO.l1_loss(x, gt, mask) * (1.0 - lam)
     l_ssim = 1.0 - HO.ssim(x, gt, mask) * lam
     (wa * l_img + wb * l_ssim).backward()
-    return float(l_img), float(l_ssim), x.grad
+    return float(l_img.detach()), float(l_ssim.detach()), x.grad
 
 
 # the kernels stream 64-column strips in bands of 34 rows, four bands per workgroup: sizes on, one over and one under those
@@ -38,7 +38,7 @@ def test_fused_loss_matches_reference_restatement(H, W, use_mask):
     x = img.clone().cuda().requires_grad_(True)
     l_img, l_ssim = fused_photometric_loss(x, gt.cuda(), None if mask is None else mask.cuda(), lam)
     (l_img + 0.7 * l_ssim).backward()
-    assert abs(float(l_img) - r_img) < 2e-6 and abs(float(l_ssim) - r_ssim) < 2e-6
+    assert abs(float(l_img.detach()) - r_img) < 2e-6 and abs(float(l_ssim.detach()) - r_ssim) < 2e-6
     assert rel_l1(x.grad, r_grad) <= 1e-4
 
 
@@ -50,12 +50,12 @@ def test_fused_loss_on_reference_golden():
     for tag, mask in (("nomask", None), ("mask", m)):
         x = a.clone().requires_grad_(True)
         l_img, l_ssim = fused_photometric_loss(x, b, mask, 1.0)          # lambda = 1 isolates SSIM: l_ssim = 1 - ssim
-        assert abs((1.0 - float(l_ssim)) - float(d[f"ssim_{tag}"])) < 2e-6
+        assert abs((1.0 - float(l_ssim.detach())) - float(d[f"ssim_{tag}"])) < 2e-6
         (1.0 - l_ssim).backward()
         assert rel_l1(x.grad, d[f"ssim_grad_{tag}"]) <= 1e-4
         x = a.clone().requires_grad_(True)
         l_img, l_ssim = fused_photometric_loss(x, b, mask, 0.0)          # lambda = 0 isolates L1
-        assert abs(float(l_img) - float(d[f"l1_{tag}"])) < 1e-6
+        assert abs(float(l_img.detach()) - float(d[f"l1_{tag}"])) < 1e-6
         l_img.backward()
         assert rel_l1(x.grad, d[f"l1_grad_{tag}"]) <= 1e-6
 
@@ -74,7 +74,7 @@ def test_fused_loss_batched_views_and_1080p_speed():
         a = l1_loss(y, gt[v], mask[v]) * 0.8
         b = 1.0 - ssim(y + 0, gt[v].clone(), mask[v]) * 0.2
         (a + b).backward()
-        assert abs(float(a) - float(l_img[v])) < 2e-6 and abs(float(b) - float(l_ssim[v])) < 2e-6
+        assert abs(float(a.detach()) - float(l_img[v].detach())) < 2e-6 and abs(float(b.detach()) - float(l_ssim[v].detach())) < 2e-6
         assert rel_l1(x.grad[v], y.grad) <= 1e-4
     # timing (informational, printed with -s): fused vs PyTorch composition, fwd+bwd per 1080p view
     def timed(fn, n=5):
