@@ -147,7 +147,7 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
                     if (!(act & (1u << (GGS_ID_BITS + q0 + q)))) continue;                   // wave-uniform: scalar branch
                     // predicated, branch-free per-pixel update: lane masks instead of nested exec juggling
                     const float dx = gx - pxf[q], dy = gy - pyf[q];
-                    const float power = fmaf(cxx * dx, dx, fmaf(cyy * dy, dy, (cxy * dx) * dy));   // log2 of the falloff
+                    const float power = ggs_falloff_log2(cxx, cxy, cyy, dx, dy);
                     const float alpha = __builtin_fminf(GGS_ALPHA_MAX, op * __builtin_amdgcn_exp2f(power));
                     const uint64_t m_ok = __builtin_amdgcn_ballot_w64(power <= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= GGS_ALPHA_MIN);
                     if (m_ok == 0) continue;
@@ -259,8 +259,8 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
                 const float4 b0 = s_rec[jb * 3 + 0], b1 = s_rec[jb * 3 + 1], b2 = s_rec[jb * 3 + 2];
                 // both alpha tests (independent of T and of each other)
                 const float dxA = a0.x - pxf, dyA = a0.y - pyf, dxB = b0.x - pxf, dyB = b0.y - pyf;
-                const float pA = fmaf(a0.z * dxA, dxA, fmaf(a1.x * dyA, dyA, (a0.w * dxA) * dyA));
-                const float pB = fmaf(b0.z * dxB, dxB, fmaf(b1.x * dyB, dyB, (b0.w * dxB) * dyB));
+                const float pA = ggs_falloff_log2(a0.z, a0.w, a1.x, dxA, dyA);
+                const float pB = ggs_falloff_log2(b0.z, b0.w, b1.x, dxB, dyB);
                 const float alA = __builtin_fminf(GGS_ALPHA_MAX, a1.y * __builtin_amdgcn_exp2f(pA));
                 const float alB = __builtin_fminf(GGS_ALPHA_MAX, b1.y * __builtin_amdgcn_exp2f(pB));
                 uint64_t okA = __builtin_amdgcn_ballot_w64(pA <= 0.f) & __builtin_amdgcn_ballot_w64(alA >= GGS_ALPHA_MIN);
@@ -473,8 +473,8 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
                 const float4 b0 = s_rec[jB * 3 + 0], b1 = s_rec[jB * 3 + 1], b2 = s_rec[jB * 3 + 2];
                 // independent of (T, B)
                 const float dxA = a0.x - pxf[0], dyA = a0.y - pyf[0], dxB = b0.x - pxf[0], dyB = b0.y - pyf[0];
-                const float pA = fmaf(a0.z * dxA, dxA, fmaf(a1.x * dyA, dyA, (a0.w * dxA) * dyA));
-                const float pB = fmaf(b0.z * dxB, dxB, fmaf(b1.x * dyB, dyB, (b0.w * dxB) * dyB));
+                const float pA = ggs_falloff_log2(a0.z, a0.w, a1.x, dxA, dyA);
+                const float pB = ggs_falloff_log2(b0.z, b0.w, b1.x, dxB, dyB);
                 const float GrA = __builtin_amdgcn_exp2f(pA), GrB = __builtin_amdgcn_exp2f(pB);
                 const float arA = __builtin_fminf(GGS_ALPHA_MAX, a1.y * GrA), arB = __builtin_fminf(GGS_ALPHA_MAX, b1.y * GrB);
                 const bool validA = (first + jA < nc[0]) & (pA <= 0.f) & (arA >= GGS_ALPHA_MIN);
@@ -537,7 +537,7 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
             for (int q = 0; q < NQ; ++q) {
                 if (!(word & (1u << (GGS_ID_BITS + q0 + q)))) continue;   // quadrant did not blend it (forward's mask)
                 const float dx = gx - pxf[q], dy = gy - pyf[q];
-                const float power = fmaf(cxx * dx, dx, fmaf(cyy * dy, dy, (cxy * dx) * dy));       // log2 of the falloff
+                const float power = ggs_falloff_log2(cxx, cxy, cyy, dx, dy);
                 const float Gr = __builtin_amdgcn_exp2f(power);
                 const float ar = __builtin_fminf(GGS_ALPHA_MAX, op * Gr);
                 const bool valid = (pos < nc[q]) & (power <= 0.f) & (ar >= GGS_ALPHA_MIN);
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(64) void ggs_k_count_blends(RenderBwdArgs a, unsign
             for (int q = 0; q < GGS_NQ; ++q) {
                 if (!(word & (1u << (GGS_ID_BITS + q)))) continue;
                 const float dx = ra.x - pxf[q], dy = ra.y - pyf[q];
-                const float power = fmaf(ra.z * dx, dx, fmaf(rb.x * dy, dy, (ra.w * dx) * dy));
+                const float power = ggs_falloff_log2(ra.z, ra.w, rb.x, dx, dy);
                 const float ar = __builtin_fminf(GGS_ALPHA_MAX, rb.y * __builtin_amdgcn_exp2f(power));
                 n += __popcll(__builtin_amdgcn_ballot_w64((first + j < nc[q]) & (power <= 0.f) & (ar >= GGS_ALPHA_MIN)));
             }

@@ -60,6 +60,21 @@ __device__ __forceinline__ float fold_rows(float q1, float q2, float r5) {
     return q1;
 }
 
+// log2 of the Gaussian falloff at offset (dx, dy) from the splat's centre, conic pre-scaled by the preprocess pass
+// (cxx, cxy, cyy) = (-log2e / 2, -log2e, -log2e / 2) x conic.  ONE definition: the forward, the backward and ggs_count_blends
+// must agree to the bit on which pixels pass the alpha test.  GGS_FALLOFF_OPS = 5: dx (cxx dx + cxy dy) + (cyy dy) dy as
+// three products and two fused multiply-adds; 6: the form of rounds 1-3 (four products, two fma).
+#ifndef GGS_FALLOFF_OPS
+#define GGS_FALLOFF_OPS 5
+#endif
+__device__ __forceinline__ float ggs_falloff_log2(float cxx, float cxy, float cyy, float dx, float dy) {
+#if GGS_FALLOFF_OPS == 5
+    return fmaf(dx, fmaf(cxx, dx, cxy * dy), (cyy * dy) * dy);
+#else
+    return fmaf(cxx * dx, dx, fmaf(cyy * dy, dy, (cxy * dx) * dy));
+#endif
+}
+
 // ---- wave reduction through an LDS transpose (GGS_BWD_RED = 1, the default) ------------------------
 // The butterfly above spends ~105 VALU-issue cycles per list entry, most of them in v_permlane32/16_swap (8.3 cycles each).
 // Here eight of the values cross the lanes through a wave-private LDS plane instead: every lane stores its 8 partials
