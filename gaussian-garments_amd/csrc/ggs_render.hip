@@ -267,8 +267,11 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
                 uint64_t okB = __builtin_amdgcn_ballot_w64(pB <= 0.f) & __builtin_amdgcn_ballot_w64(alB >= GGS_ALPHA_MIN);
                 if (!useA) okA = 0;
                 if (!useB) okB = 0;
-                uint64_t stopA = 0;
-                if (okA) {
+                // Both blends run unconditionally (w = 0 in the lanes that do not take the entry): an entry that reaches the quadrant
+                // is blended by some pixel 99 times in 100, and a wave on its own pays ~7 cycles for EVERY instruction it issues --
+                // the branches around the blends and the register moves at their joins cost more than the rare skipped blend saves.
+                uint64_t stopA;
+                {
                     const float wa = alA * T;
                     const float test_T = T - wa;
                     stopA = okA & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
@@ -284,12 +287,14 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
                     uint32_t posv;
                     asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + j + 1));
                     last = __float_as_uint(sel(app, __uint_as_float(posv), __uint_as_float(last)));
-                } else if (useA && lane == 0) {
-                    atomicAnd(&ids[first + j], ~mine);          // four waves share the word: clear only this quadrant's bit
+                }
+                if (okA == 0) {                                  // rare: nobody in this quadrant takes the entry
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) atomicAnd(&ids[first + j], ~mine);    // four waves share the word: clear only this quadrant's bit
                 }
                 okB &= ~stopA;                                   // a pixel that stopped at A no longer takes B
                 if (remaining == 0) okB = 0;
-                if (okB) {
+                {
                     const float wa = alB * T;
                     const float test_T = T - wa;
                     const uint64_t stop = okB & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
@@ -305,8 +310,10 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
                     uint32_t posv;
                     asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + jb + 1));
                     last = __float_as_uint(sel(app, __uint_as_float(posv), __uint_as_float(last)));
-                } else if (useB && lane == 0) {
-                    atomicAnd(&ids[first + jb], ~mine);
+                }
+                if (useB && okB == 0) {                          // as before: not taken (or no longer taken) here -> clear the bit
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) atomicAnd(&ids[first + jb], ~mine);
                 }
             }
         }
