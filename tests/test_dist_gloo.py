@@ -71,7 +71,11 @@ def _worker(rank, world, port, q):
     over = all_reduce_parts([lambda: slice_bucket(mine[:half]), lambda: slice_bucket(mine[half:])])
     single = slice_bucket(mine)
     all_reduce_bucket(single)
-    q.put((rank, [t.clone() for t in grads], flat.numel(), acc.clone(), den.clone(), rad.clone(), over.clone(), single.clone()))
+    # numpy arrays travel through the queue BY VALUE: torch tensors would be handed over as shared-memory file descriptors that
+    # the parent can only open while this process is alive -- a race with the exit below (EOFError / ConnectionResetError /
+    # FileNotFoundError in q.get())
+    q.put((rank, [t.numpy().copy() for t in grads], flat.numel(), acc.numpy().copy(), den.numpy().copy(), rad.numpy().copy(),
+           over.numpy().copy(), single.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -88,6 +92,9 @@ def _run_two_ranks():
         p.start()
     try:
         res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
+        as_t = torch.from_numpy
+        res = [(r, [as_t(g) for g in grads], n, as_t(acc), as_t(den), as_t(rad), as_t(over), as_t(single))
+               for r, grads, n, acc, den, rad, over, single in res]
         for p in procs:
             p.join(timeout=60)
         if any(p.exitcode != 0 for p in procs):
