@@ -12,7 +12,7 @@ from types import SimpleNamespace
 
 import torch
 
-from diff_gaussian_rasterization_depth_alpha import GaussianRasterizationSettings, GaussianRasterizer
+from diff_gaussian_rasterization_depth_alpha import GaussianRasterizationSettings, rasterize_gaussians
 
 from .sh import eval_sh
 
@@ -38,14 +38,11 @@ def _sel(t, mask):
 
 def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, mode=None, vis_mask=None):
     """Render one view.  bg_color must live on the GPU."""
-    # zero tensor that carries the gradient of the 2-D (screen-space) means back to the caller
-    screenspace_points = torch.zeros_like(pc._xyz, dtype=pc._xyz.dtype, requires_grad=True, device=pc._xyz.device) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
-    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc.active_sh_degree, pipe, bg_color,
-                                                              scaling_modifier))
+    # zero tensor that carries the gradient of the 2-D (screen-space) means back to the caller.  The reference builds it as
+    # `zeros(requires_grad=True) + 0` with retain_grad(); a leaf gets the same `.grad` through AccumulateGrad without the
+    # add node and the hook (~12 us of host time per call in a loop whose GPU work is 0.1 ms).
+    screenspace_points = torch.zeros_like(pc._xyz, dtype=pc._xyz.dtype, requires_grad=True, device=pc._xyz.device)
+    settings = _settings(viewpoint_camera, pc.active_sh_degree, pipe, bg_color, scaling_modifier)
     use_final = getattr(pc, "local_xyz", None) is not None
     means3D = pc.get_final_xyz if use_final else pc.get_xyz
     try:
@@ -86,9 +83,9 @@ def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_
         scales, rotations = _sel(scales, vis_mask), _sel(rotations, vis_mask)
         cov3D_precomp = _sel(cov3D_precomp, vis_mask)
 
-    rendered_image, radii, depth, alpha = rasterizer(
-        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacity,
-        scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+    # (GaussianRasterizer(settings)(...) of the reference = this call behind an nn.Module construction and __call__)
+    rendered_image, radii, depth, alpha = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacity, scales, rotations,
+                                                              cov3D_precomp, settings)
 
     if mask_radii is not None:
         radii = radii * mask_radii.to(radii.dtype)
@@ -104,9 +101,8 @@ def doll_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, over
                 vis_mask=None):
     """Forward-only variant used by inference.py: attribute names xyz / opacity / scaling / rotation / features,
     returns (image, depth, alpha)."""
-    screenspace_points = torch.zeros_like(pc.xyz, dtype=pc.xyz.dtype, requires_grad=True, device=pc.xyz.device) + 0
-    rasterizer = GaussianRasterizer(raster_settings=_settings(viewpoint_camera, pc.active_sh_degree, pipe, bg_color,
-                                                              scaling_modifier))
+    screenspace_points = torch.zeros_like(pc.xyz, dtype=pc.xyz.dtype, requires_grad=True, device=pc.xyz.device)
+    settings = _settings(viewpoint_camera, pc.active_sh_degree, pipe, bg_color, scaling_modifier)
     means3D, means2D, opacity = pc.xyz, screenspace_points, pc.opacity
     scales, rotations = pc.scaling, pc.rotation
     shs = colors_precomp = None
@@ -118,6 +114,6 @@ def doll_render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, over
         means3D, means2D, shs = _sel(means3D, vis_mask), _sel(means2D, vis_mask), _sel(shs, vis_mask)
         colors_precomp, opacity = _sel(colors_precomp, vis_mask), _sel(opacity, vis_mask)
         scales, rotations = _sel(scales, vis_mask), _sel(rotations, vis_mask)
-    image, radii, depth, alpha = rasterizer(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
-                                            opacities=opacity, scales=scales, rotations=rotations, cov3D_precomp=None)
+    image, radii, depth, alpha = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacity, scales, rotations, None,
+                                                     settings)
     return image, depth, alpha

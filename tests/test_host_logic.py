@@ -39,22 +39,23 @@ def test_look_at_camera_sees_target_at_principal_point():
 
 
 class _StubRasterizer:
+    """Stands in for rasterize_gaussians (what GaussianRasterizer(settings)(...) calls): records settings + arguments."""
     calls = []
 
-    def __init__(self, raster_settings):
-        self.rs = raster_settings
-
-    def __call__(self, **kw):
-        _StubRasterizer.calls.append((self.rs, kw))
-        P = kw["means3D"].shape[0]
-        H, W = self.rs.image_height, self.rs.image_width
+    @staticmethod
+    def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):
+        kw = dict(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp, opacities=opacities,
+                  scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)
+        _StubRasterizer.calls.append((settings, kw))
+        P = means3D.shape[0]
+        H, W = settings.image_height, settings.image_width
         return torch.zeros(3, H, W), torch.arange(P, dtype=torch.int32) % 2, torch.zeros(1, H, W), torch.zeros(1, H, W)
 
 
 @pytest.fixture
 def render_mod(monkeypatch):
     from ggsplat import render as RM
-    monkeypatch.setattr(RM, "GaussianRasterizer", _StubRasterizer)
+    monkeypatch.setattr(RM, "rasterize_gaussians", _StubRasterizer.rasterize)
     _StubRasterizer.calls.clear()
     return RM
 
