@@ -119,6 +119,28 @@ def test_graphed_registration_step_matches_eager(slack, lean):
     assert torch.equal(graphed.max_radii2D, eager.max_radii2D)
 
 
+def test_lean_step_without_mapped_pinned_memory_copies_its_blocks(monkeypatch):
+    """The lean step reads its parameter block and writes its result block in place in pinned host memory when that memory is
+    mapped into the device's address space; where it is not, one H2D and one D2H copy per iteration stand in.  Same numbers."""
+    from ggsplat import _lib, rasterizer as R
+    from ggsplat.inner_step import DEFAULT_OPT, GraphedRegistrationStep
+    opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "threshold_xyz": 0.3, "threshold_scale": 0.02})
+    v, f, params, cams, gts, masks = _scene(seed=3)
+    bg = torch.zeros(3, device="cuda")
+    a, b = _model(v, f, params, opt, True), _model(v, f, params, opt, True)
+    R._cap_hint.clear()
+    mapped = GraphedRegistrationStep(a, W, H, bg, opt=opt)
+    assert mapped._blk_map and mapped._out_map
+    monkeypatch.setattr(_lib, "host_mapped_pointer", lambda t: 0)
+    copied = GraphedRegistrationStep(b, W, H, bg, opt=opt)
+    assert copied._blk_map == 0 and copied._out_map == 0
+    for ci in (0, 2, 1, 3):
+        o1, o2 = mapped(cams[ci], gts[ci], masks[ci]), copied(cams[ci], gts[ci], masks[ci])
+        for k in ("img", "ssim", "xyz", "scale", "loss", "n_visible"):
+            assert abs(o1[k] - o2[k]) <= 1e-5 * max(1.0, abs(o2[k])), (ci, k, o1[k], o2[k])
+    assert a.optimizer.step_count == b.optimizer.step_count == 4
+
+
 @pytest.mark.parametrize("lean", [True, False])
 def test_graphed_mesh_only_step_without_mask(lean):
     """Later frames of a sequence: only mesh.v is optimised (training_setup(is_ff=False)), no hinge terms, no
