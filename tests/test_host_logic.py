@@ -221,3 +221,32 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "WORLD_SIZE=1" in str(e.value.code)
+
+
+def test_ctypes_mirrors_of_the_abi_structs_have_the_c_layout(tmp_path):
+    """GgsParams / GgsStepPrologue / GgsStepTail are filled in Python and read in C: sizes and field offsets must agree
+    (include/ggsplat.h compiled by gcc against the ctypes.Structure mirrors of ggsplat/_lib.py)."""
+    import ctypes as C
+    import os
+    import shutil
+    import subprocess
+    from ggsplat import _lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no C compiler")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    structs = {"GgsParams": _lib.GgsParams, "GgsStepPrologue": _lib.GgsStepPrologue, "GgsStepTail": _lib.GgsStepTail}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "ggsplat.h"', 'int main(void) {']
+    for name, cls in structs.items():
+        lines.append(f'  printf("{name} %zu\\n", sizeof({name}));')
+        for fld, _ in cls._fields_:
+            lines.append(f'  printf("{name}.{fld} %zu\\n", offsetof({name}, {fld}));')
+    lines += ['  return 0;', '}']
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-I", os.path.join(root, "include"), str(src), "-o", str(exe)], check=True)
+    got = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, cls in structs.items():
+        assert int(got[name]) == C.sizeof(cls), name
+        for fld, _ in cls._fields_:
+            assert int(got[f"{name}.{fld}"]) == getattr(cls, fld).offset, f"{name}.{fld}"
