@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--views", type=int, default=160)
     ap.add_argument("--sh-degree", type=int, default=0)
-    ap.add_argument("--chunk", type=int, default=80, help="views per launch set (per-view kernel times are flat from 16 to 160; 80 saves launches: +2 %)")
+    ap.add_argument("--chunk", type=int, default=40, help="views per launch set (per-view kernel times are flat from 16 to 160; measured round 5: 40 -> 11.19-11.23 ms, 80 -> 11.27-11.49, 20 -> 11.64 per 160-view step)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--n-around", type=int, default=200)
@@ -65,6 +65,14 @@ def parse():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every step eagerly instead of replaying the captured hipGraph of its compute part")
+    ap.add_argument("--pipeline", type=int, default=0,
+                    help="1: the backward of launch set i on a second stream beside the forward of set i + 1 (ggsplat.batch "
+                         "fwd_bwd_views(pipeline=True): two parallel branches in the captured graph)")
+    ap.add_argument("--means2d", type=int, default=1,
+                    help="1: the timed step also returns dL/dmeans2D of every view (an output of the reference's backward, a5; "
+                         "the densification statistics read it)")
+    ap.add_argument("--timing-only", action="store_true",
+                    help="print {value, ms_per_step} of the timed region and stop (sweeps, traces): no roofline / baseline legs")
     ap.add_argument("--overlap", type=int, default=0, metavar="PARTS",
                     help="N > 1: a rank's views are rendered in PARTS slices and slice i is all-reduced (asynchronously, RCCL's own "
                          "stream) while slice i + 1 is computed: only the last slice's collective stays exposed (ggsplat.dist."
@@ -209,7 +217,10 @@ def main():
     stats = {}
 
     # --overlap PARTS: the rank's views in PARTS contiguous slices, each with its own captured graph and its own bucket
-    n_parts = max(1, min(args.overlap, len(my))) if world > 1 or args.overlap > 1 else 1
+    # (the slice count is derived from the SHORTEST shard of any rank -- views[rank::N] differ by one view when N does not divide
+    # the view count -- so every rank issues the same number of all-reduces: ADVICE r4)
+    shortest = len(all_cams) // world if args.scaling == "strong" else len(all_cams)
+    n_parts = max(1, min(args.overlap, shortest)) if world > 1 or args.overlap > 1 else 1
     bounds = [round(i * len(my) / n_parts) for i in range(n_parts + 1)]
     part_cams = [{k: v[bounds[i]:bounds[i + 1]] for k, v in cams.items()} for i in range(n_parts)]
 
@@ -218,8 +229,9 @@ def main():
         the slice in launch sets of `chunk`, gradient accumulation, mesh-binding backward (ggsplat.batch.model_fwd_bwd_views:
         the C entry points without the autograd graph).  Returns the flat gradient bucket [mesh.v | _xyz | f_dc | f_rest |
         opacity | scaling | rotation] the step's all-reduce works on; the per-tensor gradients are views of it."""
-        r = batch.model_fwd_bwd_views(model, part_cams[part], bg=bg, W=W, H=H, chunk=chunk,
-                                      dL_dcolor_fn=lambda v0, v1, color: dL_buf[:v1 - v0])
+        r = batch.model_fwd_bwd_views(model, part_cams[part], bg=bg, W=W, H=H, chunk=chunk, pipeline=int(args.pipeline),
+                                      want_means2D=bool(args.means2d), dL_dcolor_fn=lambda v0, v1, color: dL_buf[:v1 - v0])
+        stats["means2D"] = r.get("means2D")
         stats["num_rendered"] = r["num_rendered"] + (stats.get("num_rendered", 0) if part else 0)
         return r["flat"]
 
@@ -317,7 +329,13 @@ def main():
         torch.save(torch.cat([g.reshape(-1) for g in stats["grads"]]).cpu(), args.dump_grads)
 
     out = None
-    if rank == 0:
+    if args.timing_only:
+        if rank == 0:
+            print(json.dumps({"value": round(views_per_sec, 2), "unit": "views/s", "ms_per_step": round(dt / args.steps * 1e3, 3),
+                              "n_gpus": world, "steps": args.steps, "views_per_step": n_views_total, "views_per_launch": chunk,
+                              "pipeline": int(args.pipeline), "means2d": int(args.means2d), "graph": graph["g"] is not None,
+                              "all_reduce_parts": n_parts}), flush=True)
+    elif rank == 0:
         # ---- per-kernel durations (HIP events on the launch stream, one launch set of `chunk` views) ----
         L = _lib.lib()
         from ggsplat import rasterizer as R

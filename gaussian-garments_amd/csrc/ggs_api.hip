@@ -277,6 +277,9 @@ void ggs_set_clear_marks_(int n, void* const* ptrs, const size_t* bytes, hipStre
         if (ptrs[i] && bytes[i]) g_marks[g_n_marks++] = ClearMark{s, (char*)ptrs[i], bytes[i]};
 }
 
+void ggs_drop_clear_marks_() { g_n_marks = 0; }
+extern "C" int ggs_step_end(void) { g_n_marks = 0; return GGS_OK; }
+
 hipError_t ggs_zero_async(void* ptr, size_t bytes, hipStream_t s) {
     if (bytes == 0) return hipSuccess;
     if (g_n_marks && take_mark(ptr, bytes, s)) return hipSuccess;
@@ -292,10 +295,12 @@ hipError_t ggs_zero_async(void* ptr, size_t bytes, hipStream_t s) {
 }
 
 namespace {
-enum { PHASE_COUNT = 1, PHASE_RENDER = 2 };
+enum { PHASE_COUNT = GGS_STAGE_COUNT, PHASE_BIN = GGS_STAGE_BIN, PHASE_COMPOSITE = GGS_STAGE_COMPOSITE,
+       PHASE_RENDER = GGS_STAGE_BIN | GGS_STAGE_COMPOSITE };
 
-// PHASE_COUNT : clear counters, preprocess (+ tile histogram), scan, work-item order  -> header.num_rendered
-// PHASE_RENDER: scatter keys, per-tile sort, composite
+// PHASE_COUNT    : clear counters, preprocess (+ tile histogram), scan, work-item order  -> header.num_rendered
+// PHASE_BIN      : scatter keys, per-tile sort
+// PHASE_COMPOSITE: composite (the only stage that writes the outputs and the per-pixel workspace)
 int forward_impl(int phases, const GgsParams* p, const float* bg, const float* means3D, const float* shs,
                  const float* colors_precomp, const float* opacities, const float* scales, const float* rotations,
                  const float* cov3D_precomp, const float* view, const float* proj, const float* campos,
@@ -373,6 +378,7 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
     }
     }  // PHASE_COUNT
     if (!(phases & PHASE_RENDER)) { prof_collect(s); return GGS_OK; }
+    if (phases & PHASE_BIN) {
     if (p->P > 0) {
         ScatterArgs a;
         a.P = p->P; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.gx16 = (p->W + 15) / 16; a.rec = (const SplatRec*)geom; a.header = header;
@@ -401,7 +407,8 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
         prof_stop(K_SORT, s);
         GGS_TRY(check("sort_tiles", s, p->debug));
     }
-    {
+    }  // PHASE_BIN
+    if (phases & PHASE_COMPOSITE) {
         RenderArgs a;
         a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.header = header;
         a.n_items = n_items; a.order = order; a.tile_count = tile_count; a.tile_offset = tile_offset; a.view_base = view_base; a.ids = ids;
@@ -433,6 +440,11 @@ extern "C" {
 int ggs_forward(GGS_FWD_PARAMS) { return forward_impl(PHASE_COUNT | PHASE_RENDER, GGS_FWD_ARGS); }
 int ggs_forward_count(GGS_FWD_PARAMS) { return forward_impl(PHASE_COUNT, GGS_FWD_ARGS); }
 int ggs_forward_render(GGS_FWD_PARAMS) { return forward_impl(PHASE_RENDER, GGS_FWD_ARGS); }
+int ggs_forward_stages(int stages, GGS_FWD_PARAMS) {
+    if (stages <= 0 || (stages & ~(PHASE_COUNT | PHASE_RENDER)))
+        return fail(GGS_ERR_ARG, "ggs_forward_stages: stages=%d is not a combination of GGS_STAGE_COUNT | _BIN | _COMPOSITE", stages);
+    return forward_impl(stages, GGS_FWD_ARGS);
+}
 int ggs_forward_spec(GGS_FWD_PARAMS, void* host_header, void* header_event) {
     if (!host_header || !header_event) return fail(GGS_ERR_ARG, "ggs_forward_spec: NULL host_header / header_event");
     GGS_TRY(forward_impl(PHASE_COUNT, GGS_FWD_ARGS));

@@ -156,3 +156,4 @@ void ggs_clear_error_();
 hipError_t ggs_zero_async(void* p, size_t bytes, hipStream_t s);
 // ggs_step_prologue's marks: ranges already zero-filled on `s` by this host thread; ggs_zero_async consumes them (ggs_api.hip)
 void ggs_set_clear_marks_(int n, void* const* ptrs, const size_t* bytes, hipStream_t s);
+void ggs_drop_clear_marks_();        // end of a step: marks nobody consumed must not outlive it

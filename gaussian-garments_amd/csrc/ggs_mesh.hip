@@ -422,7 +422,9 @@ int ggs_step_prologue(const GgsStepPrologue* d, void* stream) {
     hipLaunchKernelGGL(k_step_prologue, dim3((unsigned)blocks), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "step_prologue launch failed: %s", hipGetErrorString(e));
-    ggs_set_clear_marks_(d->n_clear, d->clear_ptr, d->clear_bytes, s);
+    void* marked[GGS_PROLOGUE_MAX_CLEAR];
+    for (int c = 0; c < d->n_clear; ++c) marked[c] = ((d->consumer_mask >> c) & 1u) ? d->clear_ptr[c] : nullptr;
+    ggs_set_clear_marks_(d->n_clear, marked, d->clear_bytes, s);
     return GGS_OK;
 }
 

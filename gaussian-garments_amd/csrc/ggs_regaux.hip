@@ -125,6 +125,8 @@ extern "C" int ggs_registration_aux_tail(int P, const float* xyz, const float* l
                                          float* max_radii2D, float* xyz_gradient_accum, float* denom, float* out_losses,
                                          void* scratch, const void* guard, const GgsStepTail* tail, void* stream) {
     ggs_clear_error_();
+    // the step's last consumer of pre-clear marks: whatever is left when this call returns -- on any path -- ends here
+    struct DropMarks { ~DropMarks() { ggs_drop_clear_marks_(); } } drop_marks_on_return;
     if (P <= 0) return GGS_OK;
     if (tail && (reinterpret_cast<uintptr_t>(tail->out_block) & 7))
         return ggs_fail_(GGS_ERR_ARG, "ggs_registration_aux_tail: out_block is not 8-byte aligned");

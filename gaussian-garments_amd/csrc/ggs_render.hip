@@ -11,33 +11,22 @@
 //     the current one is composited) and parks it in a wave-private 3 KB LDS slice;
 //   * splat j of the round is read back by all lanes with wave-uniform (broadcast) ds_read_b128:
 //     the LDS pipe issues beside the VALU (11 v_readlane per splat cost 17 % of the kernel time);
-//   * backward: the 4 pixels of a lane are summed in registers, a permlane-swap / masked-DPP butterfly
-//     folds the 9-10 values into ONE register (each total in its own lane), and a single vector
-//     float-atomic instruction adds them to the splat's GradRec.
+//   * backward: the 4 pixels of a lane are summed in registers, the nine (ten) per-splat sums cross the 64 lanes through a
+//     wave-private LDS transpose (ggs_render_common.h lds_transpose_reduce: 8 ds_write_addtid + 4 ds_read_b64 + 10 VALU; the
+//     ninth value rides a DPP chain) so that each total sits in its own lane of ONE register, and a single vector float-atomic
+//     instruction adds them to the splat's GradRec (record address formed on the scalar unit).
 //
 // Roofline: HBM nominally (algorithmic bytes per view: forward 44 N + 28 HW + 16 T, backward 20 HW + 44 N + 36 P_vis); in practice
-// both kernels are bound by VALU issue -- rocprofv3's VALUBusy is 126 % / 97 % for backward / forward (profiles/r03_sh0_valu.md),
-// their HBM traffic stays below / near the algorithmic count.  Priced per instruction class (profiles/r02_valu_issue_rates.md,
-// profiles/r02_isa_audit.md): backward ~25 cycles of per-entry overhead + ~115 per active quadrant (1.55 per entry) + ~110 for the
-// 64-lane reduction; forward ~44 per visited quadrant (2.09 per entry) + ~40 per blended one.  What other mappings would cost
-// (splat-major / systolic, larger tiles, MFMA moments) and why none was adopted: profiles/r03_bwd_mapping_study.md.
-// Build switches of the backward (A/B libraries: make RENDER_EXTRA="-DGGS_BWD_RED=0 ...", tools/dbg/build_variant.sh;
-// measurements: profiles/r04_bwd_variants.md).
-// Wave reduction of the per-splat sums: 1 = LDS transpose (ggs_render_common.h lds_transpose_reduce), 0 = the permlane-swap /
-// masked-DPP butterfly of rounds 1-3.
-#ifndef GGS_BWD_RED
-#define GGS_BWD_RED 1
-#endif
-// 1: the tile-wave backward takes the zeros of its nine per-entry sums from LDS (three broadcast reads instead of nine v_mov)
-#ifndef GGS_BWD_ZERO_LDS
-#define GGS_BWD_ZERO_LDS 1
-#endif
-// 1: ... and forms the address of the splat's gradient record on the scalar unit (no 64-bit v_mad_u64_u32 per entry)
-#ifndef GGS_BWD_SADDR
-#define GGS_BWD_SADDR 1
-#endif
-// GGS_WHATIF_NORED / GGS_WHATIF_NOREC / GGS_WHATIF_SKIPRED: what-if builds with WRONG results (no reduction / record fields fabricated on the scalar
-// unit) that price a stage by removing it; never the product library.
+// both kernels are bound by VALU issue: backward 2 685 VALU instructions per wave at 65 % lane activity, ~0.89 of the SIMDs' issue
+// cycles (profiles/r04_sh0_valu.md, r04_sh0_sq_counters.md), HBM traffic 0.64 x / 0.97 x the algorithmic count for backward /
+// forward.  Priced per instruction class with measured issue rates (profiles/r02_valu_issue_rates.md, r04_isa_audit.md): backward
+// ~45 cycles of per-entry overhead + ~115 per active quadrant (1.6-1.9 per entry) + ~60 for the reduction; forward ~44 per visited
+// quadrant (2.09 per entry) + ~40 per blended one.  Round 5 (profiles/r05_pipeline_overlap.md): run side by side on two streams the
+// two kernels DO interleave and each slows down by what the other takes -- there is no idle issue slot for a second kernel to use.
+// Mappings examined and not adopted (splat-major / systolic, larger tiles, MFMA moments, mod-8 lane folding, deferred / all-LDS
+// reductions): profiles/r03_bwd_mapping_study.md, r04_bwd_variants.md.  The variants that were BUILT for those measurements (the
+// permlane-swap butterfly of rounds 1-3, the all-values-through-LDS reduction, what-if builds that drop a stage and compute
+// wrong results on purpose) live outside this translation unit as patches: tools/dbg/variants/*.patch (tools/dbg/build_variant.sh).
 
 #include "ggs_render_common.h"
 
@@ -398,19 +387,8 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
         }
         B[q] = T[q] * (bg0 * dC0[q] + bg1 * dC1[q] + bg2 * dC2[q]);
     }
-    // GradRec field this lane adds to after the reduction (fold_rows): first lane of quad 0 / 2 / 1 of each row
-#if GGS_BWD_RED == 2
-    const int fld = lds_reduce16_field<DA>(lane);
-#elif GGS_BWD_RED == 1
+    // GradRec field this lane adds to after the reduction (lds_transpose_reduce leaves total v in lane 8 v, the ninth in lane 63)
     const int fld = lds_reduce_field<DA>(lane);
-#else
-    const int row = lane >> 4, quad = (lane >> 2) & 3;
-    int fld = -1;
-    if ((lane & 3) == 0 && quad != 3) {
-        const int pr = ((row & 1) << 1) | (row >> 1);       // rows hold fields 0, 2, 1, 3 of a 4-group
-        fld = quad == 0 ? pr : quad == 2 ? 4 + pr : row == 3 ? (DA ? 9 : 8) : (DA && row == 1) ? 8 : -1;
-    }
-#endif
     // wave max of the per-pixel contributor counts
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) maxc = max(maxc, __shfl_xor(maxc, d));
@@ -421,21 +399,13 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
 
     __shared__ float4 s_rec[64 * 3];
     RoundLds lds{s_rec};
-#if GGS_BWD_RED == 2
-    __shared__ float s_red[10 * GGS_RED16_STRIDE];
-#elif GGS_BWD_RED == 1
     __shared__ float s_red[8 * GGS_RED_STRIDE];
-#endif
-#if GGS_BWD_ZERO_LDS
     // The nine per-entry sums start from zero: nine v_mov per list entry on the pipe that bounds this kernel.  Three broadcast
     // LDS reads of a zeroed slot deliver the same zeros on the LDS pipe, right behind the record reads the entry waits for anyway.
     __shared__ float4 s_zero[2];
     if (lane < 8) reinterpret_cast<float*>(s_zero)[lane] = 0.f;
     __builtin_amdgcn_wave_barrier();
-#endif
-#if GGS_BWD_SADDR
     const int fld_bytes = fld * 4;
-#endif
     // rounds of 64 list positions, walked from the back: round r covers [64 r, 64 r + 64)
     int r = (maxc - 1) >> 6;
     Rec3 nxt = gather_round(rec, ids, r * 64, L, lane);
@@ -456,15 +426,7 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
             // recurrence is sequential (A = the entry further back, then B).
             auto reduce_add = [&](uint32_t word, float v_mx, float v_my, float v_cx, float v_cy, float v_cz, float v_op,
                                   float v_r, float v_g, float v_b, float v_dep) {
-#if GGS_BWD_RED == 2
-                const float S = lds_transpose_reduce16<DA>(s_red, lane, v_mx, v_my, v_cx, v_cy, v_cz, v_op, v_r, v_g, v_b, v_dep);
-#elif GGS_BWD_RED == 1
                 const float S = lds_transpose_reduce<DA>(s_red, lane, v_mx, v_my, v_cx, v_cy, v_cz, v_op, v_r, v_g, v_b, v_dep);
-#else
-                const float Q1 = swap16_add(swap32_add(v_mx, v_my), swap32_add(v_cx, v_cy));
-                const float Q2 = swap16_add(swap32_add(v_cz, v_op), swap32_add(v_r, v_g));
-                const float S = DA ? fold_rows<2>(Q1, Q2, swap32_add(v_b, v_dep)) : fold_rows<4>(Q1, Q2, v_b);
-#endif
                 float* dst = reinterpret_cast<float*>(acc + (word & GGS_ID_MASK));
                 if (fld >= 0) atomicAdd(dst + fld, S);
             };
@@ -518,17 +480,9 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
             const int pos = first + j;                  // list position; pixel q blended it iff pos < nc[q]
             const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, j);   // lane j gathered entry j
             if (!(word & my_bits)) continue;            // the forward blended this splat nowhere in this tile
-#if GGS_WHATIF_NOREC       // what-if: record fields fabricated on the scalar unit (wrong results: prices the LDS record reads)
-            const float wf = (float)(word & 1023u);
-            const float4 ra = make_float4((float)ox + wf * 0.01f, (float)oy + wf * 0.02f, -0.01f - wf * 1e-5f, 0.001f);
-            const float4 rb = make_float4(-0.012f - wf * 1e-5f, 0.9f, 0.5f + wf * 1e-4f, 0.25f);
-            const float4 rc = make_float4(0.75f, 1.f + wf, 0.f, 0.f);
-#else
             const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1], rc = s_rec[j * 3 + 2];
-#endif
             const float gx = ra.x, gy = ra.y, cxx = ra.z, cxy = ra.w, cyy = rb.x, op = rb.y;
             const float cr = rb.z, cg = rb.w, cb = rc.x, dep = rc.y;
-#if GGS_BWD_ZERO_LDS
             typedef float v4f __attribute__((ext_vector_type(4)));
             typedef volatile __attribute__((address_space(3))) v4f* lds_v4f;
             typedef volatile __attribute__((address_space(3))) float* lds_f;
@@ -536,10 +490,6 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
             const float z2 = ((lds_f)s_zero)[0];
             float v_mx = z0.x, v_my = z0.y, v_cx = z0.z, v_cy = z0.w, v_cz = z1.x, v_op = z1.y;
             float v_r = z1.z, v_g = z1.w, v_b = z2, v_dep = 0.f;
-#else
-            float v_mx = 0.f, v_my = 0.f, v_cx = 0.f, v_cy = 0.f, v_cz = 0.f, v_op = 0.f;
-            float v_r = 0.f, v_g = 0.f, v_b = 0.f, v_dep = 0.f;
-#endif
 #pragma unroll
             for (int q = 0; q < NQ; ++q) {
                 if (!(word & (1u << (GGS_ID_BITS + q0 + q)))) continue;   // quadrant did not blend it (forward's mask)
@@ -574,32 +524,13 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
                     v_cz = fmaf(hy, dy, v_cz);
                 }
             }
-            // rows of Q1 = (mx, cx, my, cy), of Q2 = (cz, r, op, g); R5 = b in every row (DA: b, b, depth, depth)
-#if GGS_WHATIF_NORED       // what-if: no cross-lane reduction at all (wrong results: prices the reduction)
-            const float S = ((v_mx + v_my) + (v_cx + v_cy)) + ((v_cz + v_op) + (v_r + v_g)) + v_b + v_dep;
-#elif GGS_WHATIF_SKIPRED   // what-if: GGS_WHATIF_SKIPRED sixteenths of the entries skip reduction + atomic (wrong results): what
-            // 32x16 / 32x32 tiles could save at most through their fewer (tile, splat) entries (0.80 / 0.62 of today's)
-            if ((word & 15u) < GGS_WHATIF_SKIPRED) continue;
             const float S = lds_transpose_reduce<DA>(s_red, lane, v_mx, v_my, v_cx, v_cy, v_cz, v_op, v_r, v_g, v_b, v_dep);
-#elif GGS_BWD_RED == 2
-            const float S = lds_transpose_reduce16<DA>(s_red, lane, v_mx, v_my, v_cx, v_cy, v_cz, v_op, v_r, v_g, v_b, v_dep);
-#elif GGS_BWD_RED == 1
-            const float S = lds_transpose_reduce<DA>(s_red, lane, v_mx, v_my, v_cx, v_cy, v_cz, v_op, v_r, v_g, v_b, v_dep);
-#else
-            const float Q1 = swap16_add(swap32_add(v_mx, v_my), swap32_add(v_cx, v_cy));
-            const float Q2 = swap16_add(swap32_add(v_cz, v_op), swap32_add(v_r, v_g));
-            const float S = DA ? fold_rows<2>(Q1, Q2, swap32_add(v_b, v_dep)) : fold_rows<4>(Q1, Q2, v_b);
-#endif
             const uint32_t gid = word & GGS_ID_MASK;
-#if GGS_BWD_SADDR
             // record address on the scalar unit (the id word is wave-uniform), field offset in a loop-invariant VGPR: the
             // compiler's form is a 64-bit v_mad_u64_u32 per entry
             const uint64_t rec_addr = reinterpret_cast<uint64_t>(acc) + (uint64_t)gid * sizeof(GradRec);
+            // one instruction, 9 (10) lanes, all addresses distinct
             if (fld >= 0) asm volatile("global_atomic_add_f32 %0, %1, %2" :: "v"(fld_bytes), "v"(S), "s"(rec_addr) : "memory");
-#else
-            float* dst = reinterpret_cast<float*>(acc + gid);
-            if (fld >= 0) atomicAdd(dst + fld, S);           // one instruction, 9 (10) lanes, all addresses distinct
-#endif
         }
     }
 }

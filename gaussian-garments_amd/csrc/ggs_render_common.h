@@ -10,56 +10,13 @@ __device__ __forceinline__ float dpp_fetch(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, true));
 }
 
-// ---- wave reduction of the 10 per-splat gradient values ----------------------------------------
-// gfx950 has v_permlane32_swap / v_permlane16_swap: exchanging halves (rows) between TWO registers
-// and adding folds two values at once, so the 64-lane sums of 10 values cost 28 VALU ops instead of
-// 10 x 8 with one DPP chain per value (21 ops without depth/alpha gradients):
+// gfx950's v_permlane32_swap exchanges the wave halves between TWO registers: one add then folds two values at once
 //   swap32_add(x, y)   -> lanes 0-31: 32 partials of x        | lanes 32-63: 32 partials of y
-//   swap16_add(z1, z2) -> rows 0..3 (16 lanes each): partials of (z1.lo, z2.lo, z1.hi, z2.hi)
-//   fold_rows          -> the three row-partial registers folded into one, each total in one lane
+// (the round-1-3 butterfly built on it and on v_permlane16_swap: tools/dbg/variants/r04_bwd_reductions_and_whatifs.patch)
 __device__ __forceinline__ float swap32_add(float x, float y) {
     const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
-__device__ __forceinline__ float swap16_add(float z1, float z2) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(z1), __float_as_uint(z2), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
-// Rows -> quads.  q1 and q2 hold one value per 16-lane row, r5 one value per row (or per pair of rows); DPP adds
-// with a bank mask write only part of a row, so two registers fold into one per step instead of each being
-// reduced on its own:
-//   row_ror:8  : lanes 0-7 of a row <- q1 pair sums, lanes 8-15 <- q2 pair sums;  r5 += ror8(r5)
-//   row_ror:4/12: lanes 0-3 / 8-11 <- q1 / q2 sums of 4,  lanes 4-7 / 12-15 <- r5 sums of 4
-//   quad_perm  : two more adds leave every quad with its total.
-// Result, per row: quad 0 = q1's row total, quad 2 = q2's row total; r5's totals: see the end of the function.
-// (s_nop: 2 wait states between a VALU write and a DPP read of the same VGPR; the assembler does not add them.)
-template <int R5_ROWS>
-__device__ __forceinline__ float fold_rows(float q1, float q2, float r5) {
-    asm volatile(
-        "s_nop 1\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
-        "v_add_f32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
-        "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
-        "s_nop 0\n\t"
-        "v_add_f32_dpp %0, %0, %0 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
-        "v_add_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xa"
-        : "+v"(q1), "+v"(r5) : "v"(q2));
-    q1 += dpp_fetch<0x4E, 0xf>(q1);   // quad_perm:[2,3,0,1]
-    q1 += dpp_fetch<0xB1, 0xf>(q1);   // quad_perm:[1,0,3,2]
-    // r5's row totals (quads 1 and 3) are folded across rows so that every value ends in exactly ONE lane: several
-    // lanes of one atomic instruction hitting the same address serialise in the L2 (measured: +50 % kernel time).
-    if (R5_ROWS == 2) {      // r5 = (b, b, depth, depth) by rows -> quad 1 of row 1 = b, of row 3 = depth
-        asm volatile("s_nop 1\n\t"
-                     "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0x2" : "+v"(q1));
-    } else {                 // r5 = b in all four rows -> quad 1 of row 3 = b
-        asm volatile("s_nop 1\n\t"
-                     "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xa\n\t"
-                     "s_nop 1\n\t"
-                     "v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0x8 bank_mask:0x2" : "+v"(q1));
-    }
-    return q1;
-}
-
 // log2 of the Gaussian falloff at offset (dx, dy) from the splat's centre, conic pre-scaled by the preprocess pass
 // (cxx, cxy, cyy) = (-log2e / 2, -log2e, -log2e / 2) x conic.  ONE definition: the forward, the backward and ggs_count_blends
 // must agree to the bit on which pixels pass the alpha test.  GGS_FALLOFF_OPS = 5: dx (cxx dx + cxy dy) + (cyy dy) dy as
@@ -75,9 +32,9 @@ __device__ __forceinline__ float ggs_falloff_log2(float cxx, float cxy, float cy
 #endif
 }
 
-// ---- wave reduction through an LDS transpose (GGS_BWD_RED = 1, the default) ------------------------
-// The butterfly above spends ~105 VALU-issue cycles per list entry, most of them in v_permlane32/16_swap (8.3 cycles each).
-// Here eight of the values cross the lanes through a wave-private LDS plane instead: every lane stores its 8 partials
+// ---- wave reduction of the 9 (10) per-splat gradient sums through an LDS transpose ------------------------
+// A permlane-swap / masked-DPP butterfly spends ~105 VALU-issue cycles per list entry, most of them in v_permlane32/16_swap
+// (8.3 cycles each).  Here eight of the values cross the lanes through a wave-private LDS plane instead: every lane stores its 8 partials
 // (plane [value][80] floats: bank = lane mod 32, conflict-free), then lane 8 v + s reads back the 8 partials
 // {2 s, 2 s + 1} + 16 k of value v (4 x ds_read_b64: bank = (16 v + 2 s) mod 64 within each half-wave, conflict-free), adds
 // them (7 v_add_f32) and three DPP adds inside its 8-lane group finish the sum: 10 VALU instructions for 8 values, the LDS pipe
@@ -138,47 +95,6 @@ __device__ __forceinline__ float lds_transpose_reduce(float* s_red, int lane, fl
     }
     return s;
 }
-// GGS_BWD_RED = 2: ALL nine / ten values through the plane, no DPP chain for the ninth: lane 4 v + s reads the 16 partials
-// [16 s, 16 s + 16) of value v (4 x ds_read_b128; rows 68 floats apart: conflict-free in the b128 lane groups), 15 adds and
-// two quad DPP adds.  17 VALU instructions (~51 cycles) against 16 (~58 + 6 s_nop), at twice the LDS read volume.
-#define GGS_RED16_STRIDE 68
-template <bool DA>
-__device__ __forceinline__ float lds_transpose_reduce16(float* s_red, int lane, float v0, float v1, float v2, float v3,
-                                                        float v4, float v5, float v6, float v7, float v8, float v9) {
-    typedef float v4f __attribute__((ext_vector_type(4)));
-    v4f a, b, c, d;
-    const unsigned base = (unsigned)(uintptr_t)s_red;
-    const int slot = min(lane >> 2, DA ? 9 : 8);
-    const unsigned rd = base + (slot * GGS_RED16_STRIDE + (lane & 3) * 16) * 4;
-    asm volatile("s_mov_b32 m0, %9\n\t"
-                 "s_nop 0\n\t"
-                 "ds_write_addtid_b32 %0\n\t"
-                 "ds_write_addtid_b32 %1 offset:272\n\t"
-                 "ds_write_addtid_b32 %2 offset:544\n\t"
-                 "ds_write_addtid_b32 %3 offset:816\n\t"
-                 "ds_write_addtid_b32 %4 offset:1088\n\t"
-                 "ds_write_addtid_b32 %5 offset:1360\n\t"
-                 "ds_write_addtid_b32 %6 offset:1632\n\t"
-                 "ds_write_addtid_b32 %7 offset:1904\n\t"
-                 "ds_write_addtid_b32 %8 offset:2176"
-                 :: "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(v4), "v"(v5), "v"(v6), "v"(v7), "v"(v8), "s"(base) : "memory", "m0");
-    if (DA) asm volatile("ds_write_addtid_b32 %0 offset:2448" :: "v"(v9) : "memory");
-    asm volatile("ds_read_b128 %0, %4\n\t"
-                 "ds_read_b128 %1, %4 offset:16\n\t"
-                 "ds_read_b128 %2, %4 offset:32\n\t"
-                 "ds_read_b128 %3, %4 offset:48\n\t"
-                 "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d) : "v"(rd) : "memory");
-    float s = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) + (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
-    s += dpp_fetch<0xB1, 0xf>(s);
-    s += dpp_fetch<0x4E, 0xf>(s);
-    return s;
-}
-template <bool DA>
-__device__ __forceinline__ int lds_reduce16_field(int lane) {
-    return ((lane & 3) == 0 && (lane >> 2) < (DA ? 10 : 9)) ? lane >> 2 : -1;
-}
-
 // GradRec field the lane adds to after lds_transpose_reduce (-1: none)
 template <bool DA>
 __device__ __forceinline__ int lds_reduce_field(int lane) {

@@ -29,7 +29,7 @@ class GgsStepPrologue(C.Structure):
                 ("P", C.c_int), ("F", C.c_int), ("verts", C.c_void_p), ("faces", C.c_void_p), ("binding", C.c_void_p),
                 ("local_xyz", C.c_void_p), ("log_scaling", C.c_void_p), ("raw_rot", C.c_void_p), ("bary", C.c_void_p),
                 ("xyz", C.c_void_p), ("scaling", C.c_void_p), ("rotation", C.c_void_p),
-                ("n_opacity", C.c_int), ("opacity_logit", C.c_void_p), ("opacity", C.c_void_p)]
+                ("n_opacity", C.c_int), ("opacity_logit", C.c_void_p), ("opacity", C.c_void_p), ("consumer_mask", C.c_uint)]
 
 
 class GgsStepTail(C.Structure):
@@ -53,6 +53,7 @@ _SIGS = {
     "ggs_forward": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 6),
     "ggs_forward_count": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 6),
     "ggs_forward_render": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 6),
+    "ggs_forward_stages": (C.c_int, [C.c_int, C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 6),
     "ggs_forward_spec": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 14 + [C.c_size_t] + [_PTR] * 8),
     "ggs_backward": (C.c_int, [C.POINTER(GgsParams)] + [_PTR] * 13 + [C.c_size_t] + [_PTR] * 13 + [C.c_int, _PTR]),
     "ggs_mesh_bind_forward": (C.c_int, [C.c_int, C.c_int] + [_PTR] * 11),
@@ -81,6 +82,7 @@ _SIGS = {
     "ggs_registration_aux": (C.c_int, [C.c_int] + [_PTR] * 7 + [C.c_float] * 4 + [_PTR] * 9),
     "ggs_registration_aux_tail": (C.c_int, [C.c_int] + [_PTR] * 7 + [C.c_float] * 4 + [_PTR] * 8 + [C.POINTER(GgsStepTail), _PTR]),
     "ggs_step_prologue": (C.c_int, [C.POINTER(GgsStepPrologue), _PTR]),
+    "ggs_step_end": (C.c_int, []),
     "ggs_step_clear_plan": (C.c_int, [C.POINTER(GgsParams), C.c_size_t, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "ggs_host_mapped_pointer": (C.c_int, [_PTR, C.POINTER(C.c_void_p)]),
     "ggs_visibility_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_size_t]),

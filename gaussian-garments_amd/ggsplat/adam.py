@@ -75,10 +75,20 @@ class GraphAdam:
                               "exp_avg": st["exp_avg"].clone(), "exp_avg_sq": st["exp_avg_sq"].clone()}
                 ids.append(idx)
                 idx += 1
-            groups.append({**{k: v for k, v in g.items() if k != "params"}, "betas": self.betas, "eps": self.eps, "params": ids})
+            # the keys torch.optim.Adam keeps per group, with the values this optimiser implements: a torch.optim.Adam built
+            # over the same parameters can load_state_dict() this dictionary and continue (its loader REPLACES the groups)
+            groups.append({"weight_decay": 0, "amsgrad": False, "maximize": False, "foreach": None, "capturable": False,
+                           "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                           **{k: v for k, v in g.items() if k != "params"}, "betas": self.betas, "eps": self.eps, "params": ids})
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd: Dict) -> None:
+        """Accepts its own state_dict() and torch.optim.Adam's (same layout; amsgrad / weight decay / maximize are refused:
+        this optimiser does not implement them).  The bias corrections are rebuilt from the step count with Python pow, while
+        the kernel keeps running products: a restored optimiser continues within one ulp of the original per step."""
+        for gs in sd["param_groups"]:
+            if gs.get("amsgrad") or gs.get("maximize") or gs.get("weight_decay"):
+                raise ValueError("GraphAdam.load_state_dict: amsgrad / maximize / weight_decay are not implemented")
         flat = [p for g in self.param_groups for p in g["params"]]
         for i, st in sd["state"].items():
             p = flat[int(i)]

@@ -16,18 +16,58 @@ import torch
 from . import rasterizer as R
 
 
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    """The second stream of the pipelined form (one per device, created once: a stream maps to a hardware queue)."""
+    i = dev.index if dev.index is not None else torch.cuda.current_device()
+    s = _side_streams.get(i)
+    if s is None:
+        s = _side_streams[i] = torch.cuda.Stream(device=dev)
+    return s
+
+
 def fwd_bwd_views(inputs: Dict[str, torch.Tensor], cams: Dict[str, torch.Tensor], *, bg: torch.Tensor, W: int, H: int,
                   sh_degree: int, dL_dcolor_fn, chunk: int = 32, keep_images: bool = False,
-                  want_means2D: bool = False) -> Dict[str, torch.Tensor]:
+                  want_means2D: bool = False, pipeline: int = 0) -> Dict[str, torch.Tensor]:
     """inputs: activated rasterizer inputs {means3D, opacities, shs|colors_precomp, scales+rotations|cov3D_precomp}.
     cams: stacked {view, proj, campos, tanfov} for this rank's views.
     dL_dcolor_fn(v0, v1, color[v0:v1]) -> dL/dcolor [v1-v0,3,H,W] (the loss backward of those views).
-    Returns gradients w.r.t. the activated inputs, summed over all views (+ stats)."""
+    Returns gradients w.r.t. the activated inputs, summed over all views (+ stats).
+
+    pipeline (two or more launch sets; 0 = serial, the default): launch sets software-pipelined over a SECOND stream -- for
+    fixed parameters the sets only meet in the gradient accumulators, which the backward chain owns.  1: the whole backward of
+    set i beside the whole forward of set i + 1; 2: count + bin of set i + 1 in front of the backward of set i, only its
+    compositing beside it (_fwd_bwd_views_staged).  Both work eagerly and inside a stream capture (the second stream joins the
+    capture through the events and is joined back before returning: the captured graph has parallel branches).  Same kernels,
+    same order of the backward launches; the results equal the serial form up to the order of the float atomics inside the
+    render backward (run-to-run noise of the serial form itself, ~1e-7).  MEASURED on MI355X (profiles/r05_pipeline_overlap.md):
+    neither form is faster than the serial one -- kept as an option and as the evidence for that statement."""
     V = cams["view"].shape[0]
+    dev = inputs["means3D"].device
+    if int(pipeline) == 2 and V > chunk and dev.type == "cuda" and not keep_images:
+        r = _fwd_bwd_views_staged(inputs, cams, bg=bg, W=W, H=H, sh_degree=sh_degree, dL_dcolor_fn=dL_dcolor_fn, chunk=chunk,
+                                  want_means2D=want_means2D)
+        if r is not None:
+            return r
+        pipeline = 0                        # no learnt capacity yet (first call of this shape): the serial form learns it
+    pipeline = bool(pipeline) and V > chunk and dev.type == "cuda"
     grads: Optional[Dict[str, torch.Tensor]] = None
     n_total = 0
     images: List[torch.Tensor] = []
-    m2d: List[torch.Tensor] = []          # dL/dmeans2D is per view: one [V_chunk,P,3] block per launch set
+    # dL/dmeans2D is per view: one [V,P,3] tensor, every launch set writes its own rows (no concatenation afterwards)
+    m2d = torch.empty(V, inputs["means3D"].shape[0], 3, device=dev, dtype=torch.float32) if want_means2D else None
+    main = side = None
+    keep: List = []                        # pipelined: everything the second stream still reads stays referenced until the join
+    if pipeline:
+        main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        P = inputs["means3D"].shape[0]
+        shs = inputs.get("shs")
+        # the accumulators are allocated on the caller's stream (they outlive the second stream's work)
+        grads = R.new_grads(P, shs.shape[1] if shs is not None else 0, shs is not None, inputs.get("cov3D_precomp") is not None, dev)
+        side.wait_stream(main)
+    first = True
     for v0 in range(0, V, chunk):
         v1 = min(V, v0 + chunk)
         color, radii, depth, alpha, st = R.forward_views(
@@ -37,27 +77,102 @@ def fwd_bwd_views(inputs: Dict[str, torch.Tensor], cams: Dict[str, torch.Tensor]
             tanfov=cams["tanfov"][v0:v1], bg=bg, W=W, H=H, sh_degree=sh_degree)
         n_total += st.num_rendered
         dL = dL_dcolor_fn(v0, v1, color)
-        if grads is None:
-            grads = R.backward_views(st, dL, want_means2D=want_means2D)
+        if want_means2D and grads is not None:
+            grads["means2D"] = m2d[v0:v1]
+        if pipeline:
+            ev = torch.cuda.Event()
+            ev.record(main)
+            with torch.cuda.stream(side):
+                side.wait_event(ev)
+                R.backward_views(st, dL, want_means2D=want_means2D, out=grads, accumulate=not first)
+            keep.append((st, color, radii, depth, alpha, dL))
+        elif grads is None:
+            grads = R.backward_views(st, dL, want_means2D=want_means2D, out={"means2D": m2d[v0:v1]} if want_means2D else None)
         else:
-            grads.pop("means2D", None)
             R.backward_views(st, dL, want_means2D=want_means2D, out=grads, accumulate=True)
-        if want_means2D:
-            m2d.append(grads["means2D"])
+        first = False
         if keep_images:
             images.append(color)
         del st
+    if pipeline:
+        main.wait_stream(side)
+        keep.clear()
     grads = grads or {}
     grads["num_rendered"] = n_total
-    if want_means2D and m2d:
-        grads["means2D"] = m2d[0] if len(m2d) == 1 else torch.cat(m2d)       # [V,P,3], every view of every chunk
+    if want_means2D:
+        grads["means2D"] = m2d                 # [V,P,3], every view of every launch set
     if keep_images:
         grads["images"] = torch.cat(images)
     return grads
 
 
+def _fwd_bwd_views_staged(inputs, cams, *, bg, W, H, sh_degree, dL_dcolor_fn, chunk, want_means2D):
+    """pipeline=2: the launch sets software-pipelined at STAGE granularity (rasterizer.StagedForward).  Whole-forward pipelining
+    (pipeline=1) does not overlap anything on this part: a kernel of 256-thread workgroups (preprocess, scatter, sort) queued
+    beside a flood of one-wave workgroups (the render backward) is starved until the flood drains (profiles/r05_pipeline_
+    overlap.md).  Here everything with wide workgroups of set i + 1 -- count and bin -- is queued IN FRONT of the backward of set
+    i on the caller's stream, and only the compositing of set i + 1 (one-wave workgroups, like the backward's) runs beside it
+    on the second stream.  Needs the binning capacity of this shape (learnt by an earlier serial call): returns None if there
+    is none.  No host sync inside; num_rendered is read from the device headers at the end."""
+    V = cams["view"].shape[0]
+    dev = inputs["means3D"].device
+    bounds = [(v0, min(V, v0 + chunk)) for v0 in range(0, V, chunk)]
+    P = inputs["means3D"].shape[0]
+    shs = inputs.get("shs")
+
+    def staged(v0, v1):
+        return R.StagedForward(inputs["means3D"], inputs["opacities"], shs, inputs.get("colors_precomp"), inputs.get("scales"),
+                               inputs.get("rotations"), inputs.get("cov3D_precomp"), view=cams["view"][v0:v1],
+                               proj=cams["proj"][v0:v1], campos=cams["campos"][v0:v1], tanfov=cams["tanfov"][v0:v1], bg=bg,
+                               W=W, H=H, sh_degree=sh_degree)
+    try:
+        fwds = [staged(*b) for b in bounds]
+    except R._lib.GgsError:
+        return None
+    main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    grads = R.new_grads(P, shs.shape[1] if shs is not None else 0, shs is not None, inputs.get("cov3D_precomp") is not None, dev)
+    m2d = torch.empty(V, P, 3, device=dev, dtype=torch.float32) if want_means2D else None
+    SF = R.StagedForward
+    side.wait_stream(main)
+    fwds[0].run(SF.COUNT | SF.BIN | SF.COMPOSITE)
+    composited = None                       # event: compositing of the set whose backward comes next (None: it ran on `main`)
+    for i, (v0, v1) in enumerate(bounds):
+        nxt = fwds[i + 1] if i + 1 < len(fwds) else None
+        ev_next = None
+        if nxt is not None:
+            nxt.run(SF.COUNT | SF.BIN)      # wide-workgroup kernels of set i + 1: in front of the backward of set i
+            front = torch.cuda.Event()
+            front.record(main)
+            with torch.cuda.stream(side):   # its compositing: beside that backward
+                side.wait_event(front)
+                nxt.run(SF.COMPOSITE)
+                ev_next = torch.cuda.Event()
+                ev_next.record(side)
+        if composited is not None:
+            main.wait_event(composited)
+        color = fwds[i].outputs[0]
+        dL = dL_dcolor_fn(v0, v1, color)
+        if want_means2D:
+            grads["means2D"] = m2d[v0:v1]
+        R.backward_views(fwds[i].state, dL, want_means2D=want_means2D, out=grads, accumulate=i > 0)
+        composited = ev_next
+    main.wait_stream(side)
+    grads.pop("means2D", None)
+    if want_means2D:
+        grads["means2D"] = m2d
+    if torch.cuda.is_current_stream_capturing():
+        grads["num_rendered"] = -1
+    else:
+        hdr = torch.stack([f.header for f in fwds]).cpu()          # the one host sync of the step
+        if bool((hdr[:, 1] != 0).any()):
+            R.grow_capacity(2.0)
+            return None                     # a set overflowed its binning capacity: the serial form re-sizes per call
+        grads["num_rendered"] = int(hdr[:, 0].sum())
+    return grads
+
+
 def model_fwd_bwd_views(model, cams: Dict[str, torch.Tensor], *, bg: torch.Tensor, W: int, H: int, dL_dcolor_fn,
-                        chunk: int = 32) -> Dict[str, torch.Tensor]:
+                        chunk: int = 32, pipeline: int = 0, want_means2D: bool = False) -> Dict[str, torch.Tensor]:
     """fwd_bwd_views for a MeshGaussianModel, gradients w.r.t. its PARAMETERS: mesh binding -> render forward + backward of
     every view -> mesh-binding backward, sigmoid backward of the opacities, assembled from the C entry points without the
     autograd graph (same kernels, ~20 small PyTorch launches fewer per step -- what a rank of an 8-way sharded step, 20 views,
@@ -81,7 +196,8 @@ def model_fwd_bwd_views(model, cams: Dict[str, torch.Tensor], *, bg: torch.Tenso
         K = 1 + g._features_rest.shape[1]
         shs = g._features_dc if K == 1 else torch.cat((g._features_dc, g._features_rest), dim=1)
         gr = fwd_bwd_views(dict(means3D=xyz, scales=scaling, rotations=rot, opacities=opacity, shs=shs), cams, bg=bg, W=W,
-                           H=H, sh_degree=g.active_sh_degree, chunk=chunk, dL_dcolor_fn=dL_dcolor_fn)
+                           H=H, sh_degree=g.active_sh_degree, chunk=chunk, dL_dcolor_fn=dL_dcolor_fn, pipeline=pipeline,
+                           want_means2D=want_means2D)
         d_verts = torch.zeros_like(verts)
         d_xyz, d_ls, d_rr = torch.empty_like(g._xyz), torch.empty_like(g._scaling), torch.empty_like(g._rotation)
         check(L.ggs_mesh_bind_backward(P, Fn, ptr(verts), ptr(faces), ptr(binding), ptr(g._xyz), ptr(g._scaling),
@@ -92,4 +208,7 @@ def model_fwd_bwd_views(model, cams: Dict[str, torch.Tensor], *, bg: torch.Tenso
         gs = gr["shs"]
         parts = [d_verts, d_xyz, gs if K == 1 else gs[:, :1], gs[:, 1:], d_op, d_ls, d_rr]
         flat = torch.cat([t.reshape(-1) for t in parts])
-    return {"flat": flat, "num_rendered": gr["num_rendered"]}
+    out = {"flat": flat, "num_rendered": gr["num_rendered"]}
+    if want_means2D:
+        out["means2D"] = gr["means2D"]          # [V,P,3] screen-space gradients of every view (densification statistics)
+    return out

@@ -297,6 +297,14 @@ class GraphedRegistrationStep:
         stream = stream_ptr(dev)
         H, W = cam.image_height, cam.image_width
         P, Fn = g._xyz.shape[0], g.mesh.f.shape[0]
+        try:
+            return self._lean_calls(L, g, opt, cam, dev, stream, H, W, P, Fn, optimizer_step, track)
+        finally:
+            L.ggs_step_end()            # a step that raised half way must not leave pre-clear marks behind (include/ggsplat.h)
+
+    def _lean_calls(self, L, g, opt, cam, dev, stream, H, W, P, Fn, optimizer_step: bool, track: bool):
+        import ctypes as C
+        from ._lib import GgsStepPrologue, GgsStepTail, check, ptr
         with torch.no_grad():
             verts, faces, binding, bary = g.mesh.v, g.mesh.f, g.binding, g.gs_bc
             xyz, scaling, rot = torch.empty_like(g._xyz), torch.empty_like(g._scaling), torch.empty_like(g._rotation)
@@ -305,11 +313,15 @@ class GraphedRegistrationStep:
             K = 1 + g._features_rest.shape[1]
             ws = R.plan_step(P, K, g.active_sh_degree, W, H, 1, dev)
             pro = GgsStepPrologue()
-            clears = ((ws.bin, ws.bin_clear), (ws.scratch, ws.scratch_clear), (self._sums, 8), (self._aux_scratch, 16),
-                      (d_verts, d_verts.numel() * 4))
+            # (range, bytes, does a later call of this step zero-fill it itself?) -- only those are MARKED for their consumer:
+            # ggs_forward (binning counters), ggs_backward (gradient records), ggs_photometric_forward_roi (sums) and, when the
+            # hinge terms run, ggs_registration_aux_tail (its 16-byte sums); nothing in the library clears dL/dvertices
+            clears = ((ws.bin, ws.bin_clear, True), (ws.scratch, ws.scratch_clear, True), (self._sums, 8, True),
+                      (self._aux_scratch, 16, bool(self.fft)), (d_verts, d_verts.numel() * 4, False))
             pro.n_clear = len(clears)
-            for i, (t, n) in enumerate(clears):
+            for i, (t, n, consumed) in enumerate(clears):
                 pro.clear_ptr[i], pro.clear_bytes[i] = t.data_ptr(), n
+                pro.consumer_mask |= int(consumed) << i
             if self._blk_map:
                 pro.copy_src, pro.copy_dst, pro.copy_bytes = self._blk_map, self._blk.data_ptr(), 176
             pro.P, pro.F = P, Fn
@@ -415,17 +427,32 @@ class GraphedRegistrationStep:
         self._captured = self._identity()
 
     def _identity(self):
-        """The tensors whose ADDRESSES a captured step holds: parameters, mesh connectivity, binding, statistics.  Density
-        control (ggsplat.densify) and load_ply replace them with new tensors of another size; the next call re-captures."""
+        """The tensors whose ADDRESSES a captured step holds: parameters, mesh connectivity, binding, statistics and the
+        optimiser's per-parameter state (moments, step words).  Density control (ggsplat.densify) and load_ply replace them
+        with new tensors; the next call re-captures.  The list holds STRONG REFERENCES and is compared with `is`
+        (_same_tensors): an (id, data_ptr, shape) fingerprint can be reproduced by the caching allocator and CPython handing
+        the addresses of dead tensors to new ones -- a density step that selects nothing keeps every shape -- while the
+        moments land somewhere else (MeshGaussianModel._bind documents the same pitfall)."""
         g = self.g
         ts = list(g.parameters()) + [g.mesh.f, g.binding, g.gs_bc, g.max_radii2D, g.xyz_gradient_accum, g.denom]
-        return tuple((id(t), None if t is None else t.data_ptr(), None if t is None else tuple(t.shape)) for t in ts)
+        opt = getattr(self, "optimizer", None) or g.optimizer
+        for group in (opt.param_groups if opt is not None else ()):
+            for p in group["params"]:
+                st = opt.state.get(p)
+                ts.append(p)
+                if st:
+                    ts.extend(v for v in st.values() if torch.is_tensor(v))
+        return ts
+
+    @staticmethod
+    def _same_tensors(a, b) -> bool:
+        return a is not None and len(a) == len(b) and all(x is y for x, y in zip(a, b))
 
     def __call__(self, cam, gt_image, mask=None) -> Dict[str, torch.Tensor]:
         """One optimisation step.  Returns {"loss", "img", "ssim", ...}: Python floats (lean) or device scalars that the
         next call overwrites (lean=False)."""
         self._load(cam, gt_image, mask)
-        if self.graph is not None and self._captured != self._identity():
+        if self.graph is not None and not self._same_tensors(self._captured, self._identity()):
             self.graph = None                       # P changed under the graph (densify / prune): capture the new shapes
             self.recaptures += 1
         if self.graph is None:

@@ -171,13 +171,10 @@ class ForwardState:
                  "campos", "tanfov", "geom", "bin", "cap", "img", "num_rendered", "header")
 
 
-def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, *, view, proj, campos,
-                  tanfov, bg, W: int, H: int, sh_degree: int, scale_modifier: float = 1.0, debug: bool = False,
-                  keep_state: bool = True, workspaces: Optional[StepWorkspaces] = None):
-    """Rasterize V views.  view/proj [V,16], campos [V,3], tanfov [V,2], bg [V,3] or [3].
-    Returns color [V,3,H,W], radii [V,P] int32, depth [V,H,W], alpha [V,H,W], state.
-    workspaces: buffers from plan_step() for this shape (used as long as their capacity is the one the call runs with)."""
-    L = lib()
+def _prep_forward(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, view, proj, campos, tanfov, bg,
+                  W: int, H: int, sh_degree: int, scale_modifier: float, debug: bool):
+    """Input normalisation shared by forward_views and StagedForward: float32 / contiguous tensors on the GPU, the upstream
+    empty-tensor convention, stacked camera blocks, GgsParams and the four output tensors."""
     dev = means3D.device
     if dev.type != "cuda":
         raise _lib.GgsError("ggsplat: tensors must live on the GPU (there is no CPU path in the product)")
@@ -208,6 +205,20 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
     depth = torch.empty(V, H, W, device=dev, dtype=torch.float32)
     alpha = torch.empty(V, H, W, device=dev, dtype=torch.float32)
     radii = torch.empty(V, P, device=dev, dtype=torch.int32)
+    return (dev, P, V, prm, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, view, proj, campos, tanfov,
+            bg, color, depth, alpha, radii)
+
+
+def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, *, view, proj, campos,
+                  tanfov, bg, W: int, H: int, sh_degree: int, scale_modifier: float = 1.0, debug: bool = False,
+                  keep_state: bool = True, workspaces: Optional[StepWorkspaces] = None):
+    """Rasterize V views.  view/proj [V,16], campos [V,3], tanfov [V,2], bg [V,3] or [3].
+    Returns color [V,3,H,W], radii [V,P] int32, depth [V,H,W], alpha [V,H,W], state.
+    workspaces: buffers from plan_step() for this shape (used as long as their capacity is the one the call runs with)."""
+    L = lib()
+    (dev, P, V, prm, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, view, proj, campos, tanfov, bg,
+     color, depth, alpha, radii) = _prep_forward(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, view,
+                                                 proj, campos, tanfov, bg, W, H, sh_degree, scale_modifier, debug)
 
     key = (dev.index, P, W, H, V)
     cap = _cap_hint.get(key, max(8 * P * V, 1 << 16))
@@ -275,6 +286,61 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
     return color, radii, depth, alpha, st
 
 
+class StagedForward:
+    """One forward of V views whose three stages (ggs_forward_stages: count | bin | composite) the caller queues itself -- on
+    one stream or on several it orders with events (ggsplat.batch.fwd_bwd_views(pipeline=2)).  No host sync: the call runs with
+    the binning capacity learnt by earlier forward_views calls of the same shape (raises if there was none) and leaves its
+    overflow word on the device (`header`); a forward that overflowed composites every tile as empty and every kernel
+    behind it is guarded, so the caller checks `header[1]` once per step and falls back to forward_views."""
+
+    def __init__(self, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, *, view, proj, campos, tanfov,
+                 bg, W: int, H: int, sh_degree: int, scale_modifier: float = 1.0):
+        L = lib()
+        (dev, P, V, prm, means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, view, proj, campos, tanfov, bg,
+         color, depth, alpha, radii) = _prep_forward(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp,
+                                                     view, proj, campos, tanfov, bg, W, H, sh_degree, scale_modifier, False)
+        key = (dev.index, P, W, H, V)
+        if key not in _cap_hint:
+            raise _lib.GgsError("ggsplat: run this configuration through forward_views once before staging it "
+                                "(the binning capacity is learnt from an eager call)")
+        cap = _cap_hint[key]
+        gsz, isz, bsz = _workspace_sizes(L, prm, cap)
+        new = (lambda n: torch.empty(n, device=dev, dtype=torch.uint8))
+        geom, img, binb = new(gsz), new(isz), new(bsz)
+        self.dev, self.outputs = dev, (color, radii, depth, alpha)
+        self._args = (C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales),
+                      ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov), ptr(geom),
+                      ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha), ptr(radii))
+        self.header = binb[:16].view(torch.int64)
+        st = self.state = ForwardState()
+        st.prm, st.bg, st.means3D, st.shs, st.colors, st.opac = prm, bg, means3D, shs, colors_precomp, opacities
+        st.scales, st.rots, st.cov, st.view, st.proj, st.campos, st.tanfov = scales, rotations, cov3D_precomp, view, proj, campos, tanfov
+        st.geom, st.bin, st.cap, st.img, st.num_rendered, st.header = geom, binb, cap, img, -1, self.header
+        if torch.cuda.is_current_stream_capturing():
+            _capture_headers.append(self.header)
+
+    COUNT, BIN, COMPOSITE = 1, 2, 4
+
+    def run(self, stages: int) -> None:
+        """Queue the given stages on PyTorch's current stream."""
+        check(lib().ggs_forward_stages(int(stages), *self._args, _lib.stream_ptr(self.dev)), "ggs_forward_stages")
+
+
+def new_grads(P: int, K: int, has_shs: bool, has_cov: bool, dev) -> Dict[str, torch.Tensor]:
+    """The (uninitialised) gradient tensors ggs_backward writes for P Gaussians in the given input mode."""
+    new = (lambda *s: torch.empty(*s, device=dev, dtype=torch.float32))
+    g = {"means3D": new(P, 3), "opacities": new(P, 1)}
+    if has_shs:
+        g["shs"] = new(P, K, 3)
+    else:
+        g["colors_precomp"] = new(P, 3)
+    if has_cov:
+        g["cov3D_precomp"] = new(P, 6)
+    else:
+        g["scales"], g["rotations"] = new(P, 3), new(P, 4)
+    return g
+
+
 def backward_views(st: ForwardState, dL_dcolor, dL_ddepth=None, dL_dalpha=None, want_means2D: bool = True,
                    out: Optional[Dict[str, torch.Tensor]] = None, accumulate: bool = False,
                    scratch: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
@@ -285,22 +351,12 @@ def backward_views(st: ForwardState, dL_dcolor, dL_ddepth=None, dL_dalpha=None, 
     P, K, V = prm.P, prm.K, prm.n_views
     dL_dcolor = _f32c(dL_dcolor)
     dL_ddepth, dL_dalpha = _f32c(dL_ddepth), _f32c(dL_dalpha)
-    new = (lambda *s: torch.empty(*s, device=dev, dtype=torch.float32))
     g = out if out is not None else {}
     if "means3D" not in g:
-        g["means3D"] = new(P, 3)
-        g["opacities"] = new(P, 1)
-        if st.shs is not None:
-            g["shs"] = new(P, K, 3)
-        else:
-            g["colors_precomp"] = new(P, 3)
-        if st.cov is not None:
-            g["cov3D_precomp"] = new(P, 6)
-        else:
-            g["scales"], g["rotations"] = new(P, 3), new(P, 4)
+        g.update(new_grads(P, K, st.shs is not None, st.cov is not None, dev))
         accumulate = False
     if want_means2D and "means2D" not in g:
-        g["means2D"] = new(V, P, 3)
+        g["means2D"] = torch.empty(V, P, 3, device=dev, dtype=torch.float32)
     k = (P, K, V)
     nbytes = _bwd_scratch.get(k)
     if nbytes is None:

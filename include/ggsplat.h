@@ -144,6 +144,25 @@ int ggs_forward_render(const GgsParams* prm, const float* bg, const float* means
                        const float* rotations, const float* cov3D_precomp, const float* view, const float* proj,
                        const float* campos, const float* tanfov, void* geom, void* bin, size_t bin_capacity,
                        void* img, float* out_color, float* out_depth, float* out_alpha, int* radii, void* stream);
+/*
+ * Any contiguous run of the forward's three stages, same argument list behind the stage mask:
+ *   GGS_STAGE_COUNT     = ggs_forward_count;
+ *   GGS_STAGE_BIN       = key scatter + per-tile sort (reads the records and counters of the count stage, writes the lists);
+ *   GGS_STAGE_COMPOSITE = compositing (reads records + lists; the only stage that writes out_color / out_depth / out_alpha and
+ *                         the per-pixel workspace `img`).
+ * ggs_forward_render == GGS_STAGE_BIN | GGS_STAGE_COMPOSITE.  For callers that software-pipeline launch sets: the binning of
+ * set i + 1 can be queued in front of the backward of set i and its compositing beside it on another stream
+ * (ggsplat.batch.fwd_bwd_views(pipeline=2); measurements: profiles/r05_pipeline_overlap.md).  The stages of one forward must run in
+ * order on streams ordered by the caller.  No reference counterpart (the upstream forward is one call).
+ */
+#define GGS_STAGE_COUNT 1
+#define GGS_STAGE_BIN 2
+#define GGS_STAGE_COMPOSITE 4
+int ggs_forward_stages(int stages, const GgsParams* prm, const float* bg, const float* means3D, const float* shs,
+                       const float* colors_precomp, const float* opacities, const float* scales,
+                       const float* rotations, const float* cov3D_precomp, const float* view, const float* proj,
+                       const float* campos, const float* tanfov, void* geom, void* bin, size_t bin_capacity,
+                       void* img, float* out_color, float* out_depth, float* out_alpha, int* radii, void* stream);
 
 /*
  * Backward.  dL_dcolor [V][3][H][W]; dL_ddepth / dL_dalpha [V][H][W] or NULL (zero).
@@ -343,9 +362,13 @@ int ggs_registration_aux_tail(int P, const float* xyz, const float* log_scaling,
  *     host thread and `stream`: the next library call on that thread and stream that would itself zero-fill a range starting
  *     at the same address and no longer -- the binning counters of ggs_forward* (ggs_step_clear_plan: bin_bytes at `bin`), the
  *     gradient records of ggs_backward (backward_scratch_bytes at `scratch`), the sums of ggs_photometric_forward* (8 n_views
- *     bytes), the 16-byte scratch of ggs_registration_aux -- consumes the mark and skips its own fill launch.  Marks nobody
- *     consumed are dropped by the next ggs_step_prologue of the thread.  The caller must not write to a marked range before its
- *     consumer ran.  Ranges without a consumer are simply zero-filled (e.g. dL_dverts of ggs_mesh_bind_backward).
+ *     bytes), the 16-byte scratch of ggs_registration_aux -- consumes the mark and skips its own fill launch.  Only the ranges
+ *     flagged in `consumer_mask` are marked; the others are simply zero-filled (e.g. dL_dverts of ggs_mesh_bind_backward, which
+ *     no library call clears).  Marks END WITH THE STEP: ggs_registration_aux* (the step's last library call but the optimiser
+ *     update) drops whatever is left after consuming its own, ggs_step_end() does the same for steps shaped differently or cut
+ *     short by an error, and so does the next ggs_step_prologue of the thread -- a mark can never meet a zero fill of a later,
+ *     unrelated call that happens to start at the same address.  The caller must not write to a marked range
+ *     before its consumer ran.
  *   copy_src -> copy_dst, copy_bytes <= 1024 (4-byte aligned; 0: none): a small block copy; copy_src may be host-mapped
  *     page-locked memory, read in place (the per-iteration camera / pointer block without a copy launch).
  *   P, F, verts ... rotation: the arguments of ggs_mesh_bind_forward (P = 0: no binding).
@@ -362,8 +385,11 @@ typedef struct GgsStepPrologue {
     const float *local_xyz, *log_scaling, *raw_rot, *bary;
     float *xyz, *scaling, *rotation;
     int n_opacity; const float* opacity_logit; float* opacity;
+    unsigned consumer_mask;      /* bit i: range i is zero-filled by a later library call of this step -> mark it (see above) */
 } GgsStepPrologue;
 int ggs_step_prologue(const GgsStepPrologue* d, void* stream);
+/* Drops the marks the calling thread still holds (a step that raised half way, a step without ggs_registration_aux*). */
+int ggs_step_end(void);
 /* Leading bytes of `bin` that ggs_forward* and of `scratch` that ggs_backward zero-fill first. */
 int ggs_step_clear_plan(const GgsParams* p, size_t bin_capacity, size_t* bin_bytes, size_t* backward_scratch_bytes);
 /* Device address of mapped page-locked host memory (hipHostMalloc: PyTorch's pinned tensors); GGS_ERR_HIP if it is not. */

@@ -194,6 +194,330 @@ def cov3d_golden():
     np.savez(os.path.join(OUT, "cov3d.npz"), **rec)
 
 
+# ---- the reference's MODEL CLASSES and render() run on the CPU (rows a1, a13: host logic pinned by import) ---------------------
+class _CpuTorch:
+    """Stands in for the name `torch` inside a reference module: everything is torch's, except that factory calls drop the
+    hard-coded device="cuda" (scene/gaussian_model.py, scene/mesh_gaussian_model.py, gaussian_renderer/__init__.py allocate
+    that way), and `normal` returns mean + z * std with z drawn from a seeded CPU generator and RECORDED -- the test feeds the
+    same z to the product, so the reference's CPU run and the product's GPU run sample the same children."""
+
+    def __init__(self, seed=0):
+        self._gen = torch.Generator().manual_seed(seed)
+        self.draws = []
+
+    def __getattr__(self, k):
+        return getattr(torch, k)
+
+    @staticmethod
+    def _strip(kw):
+        if str(kw.get("device", "")).startswith("cuda"):
+            kw.pop("device")
+        return kw
+
+    def zeros(self, *a, **kw): return torch.zeros(*a, **self._strip(kw))
+    def ones(self, *a, **kw): return torch.ones(*a, **self._strip(kw))
+    def zeros_like(self, *a, **kw): return torch.zeros_like(*a, **self._strip(kw))
+    def ones_like(self, *a, **kw): return torch.ones_like(*a, **self._strip(kw))
+    def tensor(self, *a, **kw): return torch.tensor(*a, **self._strip(kw))
+    def arange(self, *a, **kw): return torch.arange(*a, **self._strip(kw))
+
+    def normal(self, mean, std):
+        z = torch.randn(std.shape, generator=self._gen)
+        self.draws.append(z)
+        return mean + z * std
+
+
+def _import_reference_models():
+    """Imports scene.gaussian_model, scene.mesh_gaussian_model and gaussian_renderer from /root/reference on a machine without
+    their third-party dependencies: empty stand-in modules are registered for the names the import statements need (trimesh,
+    smplx, plyfile, open3d, roma, simple_knn, munch-based utils.defaults, the rasterizer extension).  NOTHING of a stand-in is
+    ever called by the functions the goldens run -- with one exception that is the point of the exercise: the rasterizer stand-in
+    RECORDS the arguments render() hands to it.  `scene` is registered as a bare package (its __init__ imports the whole
+    training stack) whose submodules load from the reference's own files."""
+    import types
+
+    def stub(name, **attrs):
+        m = sys.modules.get(name)
+        if m is None or not getattr(m, "__golden_stub__", False):
+            m = types.ModuleType(name)
+            m.__golden_stub__ = True
+            sys.modules[name] = m
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+
+    def never(*a, **kw):
+        raise AssertionError("a stand-in for a missing third-party module was CALLED while generating goldens")
+    for name in ("trimesh", "smplx", "open3d", "simple_knn"):
+        stub(name)
+    stub("plyfile", PlyData=never, PlyElement=never)
+    stub("simple_knn._C", distCUDA2=never)
+    stub("roma", rotmat_to_unitquat=never, quat_xyzw_to_wxyz=never, quat_wxyz_to_xyzw=never, quat_product=never,
+         unitquat_to_rotmat=never)
+    stub("utils.defaults", DEFAULTS=types.SimpleNamespace(output_root="", data_root="", aux_root="", stage1="stage1",
+                                                          stage2="stage2", stage3="stage3"))
+    pkg = stub("scene")
+    pkg.__path__ = [os.path.join(REF, "scene")]                      # submodules come from the reference's files
+    stub("scene.cameras", Camera=object)
+    rec = stub("diff_gaussian_rasterization_depth_alpha")
+    import importlib
+    gm = importlib.import_module("scene.gaussian_model")
+    mgm = importlib.import_module("scene.mesh_gaussian_model")
+    return gm, mgm, rec
+
+
+def _densify_fixture(seed=0):
+    """2000 faces (a 40 x 25 tube), one Gaussian per face, SH degree 1: plain torch, no dependency on the product package."""
+    g = torch.Generator().manual_seed(seed)
+    na, nr = 40, 25
+    th = torch.arange(na).float() / na * 2 * math.pi
+    rows = []
+    for r in range(nr + 1):
+        rad = 0.35 + 0.25 * r / nr
+        rows.append(torch.stack([rad * torch.cos(th), torch.full((na,), 0.9 - 1.0 * r / nr), rad * torch.sin(th)], 1))
+    verts = torch.cat(rows) + torch.randn((nr + 1) * na, 3, generator=g) * 2e-3
+    faces = []
+    for r in range(nr):
+        for a in range(na):
+            i0, i1 = r * na + a, r * na + (a + 1) % na
+            faces.append([i0, i1, i0 + na] if (r + a) % 2 == 0 else [i1, i1 + na, i0 + na])
+    faces = torch.tensor(faces[:2000], dtype=torch.long)
+    P = faces.shape[0]
+    prm = {"_xyz": torch.randn(P, 3, generator=g) * 0.05,
+           "_features_dc": torch.randn(P, 1, 3, generator=g) * 0.5,
+           "_features_rest": torch.randn(P, 3, 3, generator=g) * 0.1,
+           "_opacity": torch.randn(P, 1, generator=g) * 1.5,
+           "_scaling": torch.log(torch.rand(P, 3, generator=g) * 0.6 + 0.25),
+           "_rotation": torch.randn(P, 4, generator=g)}
+    prm["_opacity"][::17] = -8.0                                       # below min_opacity: pruned
+    grads = {k: torch.randn(v.shape, generator=g) * 1e-3 for k, v in prm.items()}
+    grads["vertex"] = torch.randn(verts.shape, generator=g) * 1e-3
+    stats = {"accum": torch.rand(P, 1, generator=g) * 4e-4, "denom": torch.randint(0, 3, (P, 1), generator=g).float(),
+             "radii": torch.rand(P, generator=g) * 30}
+    return verts, faces, prm, grads, stats
+
+
+_OPT = dict(percent_dense=0.01, position_lr_init=0.00016, position_lr_final=0.0000016, position_lr_delay_mult=0.01,
+            position_lr_max_steps=30_000, feature_lr=0.0025, opacity_lr=0.05, scaling_lr=0.005, rotation_lr=0.001)
+
+
+def _reference_model(gm, mgm, verts, faces, prm, sh_degree=1):
+    """A reference MeshGaussianModel WITHOUT its constructor (which reads a template / point cloud from disk,
+    scene/mesh_gaussian_model.py:48-88): GaussianModel.__init__ + the fields the constructor would have set."""
+    import types
+    from torch import nn
+    m = object.__new__(mgm.MeshGaussianModel)
+    gm.GaussianModel.__init__(m, sh_degree)
+    m.mesh = types.SimpleNamespace(v=nn.Parameter(verts.clone()), f=faces.clone())
+    for k, v in prm.items():
+        setattr(m, k, nn.Parameter(v.clone()))
+    m.binding = torch.arange(faces.shape[0])
+    m.binding_counter = torch.ones(faces.shape[0], dtype=torch.int32)
+    m.max_radii2D = torch.zeros(faces.shape[0])
+    m.spatial_lr_scale = 1.0
+    # update_face_coor (scene/mesh_gaussian_model.py:90-95) minus its roma call (the face quaternion, which density control
+    # never reads): the same two statements with the reference's own compute_face_orientation
+    m.face_center = m.mesh.v[m.mesh.f].mean(1)
+    m.face_orien_mat, m.face_scaling = compute_face_orientation(m.mesh.v, m.mesh.f, return_scale=True)
+    return m
+
+
+def model_golden():
+    """densify.npz / training_setup.npz: the reference's own training_setup, add_densification_stats, densify_and_prune
+    (clone, split, prune with the never-empty-a-face rule) and prune_points run on a seeded 2000-Gaussian fixture."""
+    import types
+    gm, mgm, _ = _import_reference_models()
+    import utils.general_utils as GU
+    opt = types.SimpleNamespace(**_OPT)
+    rec = {}
+    # ---- training_setup: group names / learning rates / Adam hyper-parameters, is_ff True and False --------------------
+    verts, faces, prm, grads, stats = _densify_fixture()
+    ts = {}
+    for is_ff in (True, False):
+        px = _CpuTorch()
+        gm.torch = mgm.torch = GU.torch = px
+        try:
+            m = _reference_model(gm, mgm, verts, faces, prm)
+            m.training_setup(opt, is_ff)
+        finally:
+            gm.torch = mgm.torch = GU.torch = torch
+        tag = "ff" if is_ff else "mesh"
+        ts[f"{tag}_names"] = np.array([g["name"] for g in m.optimizer.param_groups])
+        ts[f"{tag}_lr"] = np.array([g["lr"] for g in m.optimizer.param_groups], dtype=np.float64)
+        ts[f"{tag}_eps"] = np.array([g["eps"] for g in m.optimizer.param_groups], dtype=np.float64)
+        ts[f"{tag}_betas"] = np.array([g["betas"] for g in m.optimizer.param_groups], dtype=np.float64)
+        ts[f"{tag}_numel"] = np.array([g["params"][0].numel() for g in m.optimizer.param_groups])
+        ts[f"{tag}_xyz_lr_at"] = np.array([m.xyz_scheduler_args(i) for i in (0, 1, 100, 7000, 30000)], dtype=np.float64)
+        ts[f"{tag}_percent_dense"] = np.array(m.percent_dense)
+        ts[f"{tag}_stats_shapes"] = np.array([*m.xyz_gradient_accum.shape, *m.denom.shape])
+    ts["opt_keys"], ts["opt_vals"] = np.array(list(_OPT)), np.array(list(_OPT.values()), dtype=np.float64)
+    np.savez(os.path.join(OUT, "training_setup.npz"), **ts)
+
+    # ---- density control --------------------------------------------------------------------------------------------
+    rec.update({"verts": verts.numpy(), "faces": faces.numpy(), **{"p" + k: v.numpy() for k, v in prm.items()},
+                **{"g_" + k: v.numpy() for k, v in grads.items()}, **{"s_" + k: v.numpy() for k, v in stats.items()}})
+    rec["hyper"] = np.array([0.0002, 0.005, 3.0], dtype=np.float64)       # max_grad, min_opacity, extent
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+
+    def snapshot(m, tag):
+        out = {}
+        for n in names:
+            p_ = getattr(m, n)
+            out[f"{tag}{n}"] = p_.detach().numpy().copy()
+            st = m.optimizer.state[p_]
+            out[f"{tag}{n}_m1"], out[f"{tag}{n}_m2"] = st["exp_avg"].numpy().copy(), st["exp_avg_sq"].numpy().copy()
+        out[f"{tag}_binding"], out[f"{tag}_counter"] = m.binding.numpy().copy(), m.binding_counter.numpy().copy()
+        out[f"{tag}_accum"], out[f"{tag}_denom"] = m.xyz_gradient_accum.numpy().copy(), m.denom.numpy().copy()
+        out[f"{tag}_radii"] = m.max_radii2D.numpy().copy()
+        return out
+
+    def prepared(px):
+        m = _reference_model(gm, mgm, verts, faces, prm)
+        m.training_setup(opt, True)
+        for n in names:
+            getattr(m, n).grad = grads[n].clone()
+        m.mesh.v.grad = grads["vertex"].clone()
+        m.optimizer.step()                                             # recognisable Adam moments (lr as set up: parameters move)
+        m.optimizer.zero_grad(set_to_none=True)
+        # the frames follow mesh.v, which the step just moved (the s2 loop calls update_face_coor every iteration)
+        m.face_center = m.mesh.v[m.mesh.f].mean(1)
+        m.face_orien_mat, m.face_scaling = compute_face_orientation(m.mesh.v, m.mesh.f, return_scale=True)
+        return m
+
+    for tag, max_screen in (("none", None), ("s20", 20)):
+        px = _CpuTorch(seed=123)
+        gm.torch = mgm.torch = GU.torch = px
+        try:
+            with torch.no_grad():
+                m = prepared(px)
+            if tag == "none":
+                rec.update(snapshot(m, "pre"))                         # the state density control starts from (after one Adam step)
+                rec["pre_verts"] = m.mesh.v.detach().numpy().copy()
+                # add_densification_stats (scene/gaussian_model.py:410-412) on a seeded screen-space gradient / filter
+                g2 = torch.Generator().manual_seed(77)
+                vsp = types.SimpleNamespace(grad=torch.randn(faces.shape[0], 3, generator=g2) * 1e-3)
+                filt = torch.rand(faces.shape[0], generator=g2) > 0.4
+                with torch.no_grad():
+                    m.add_densification_stats(vsp, filt)
+                    m.add_densification_stats(vsp, filt)
+                rec["ads_grad"], rec["ads_filter"] = vsp.grad.numpy(), filt.numpy()
+                rec["ads_accum"], rec["ads_denom"] = m.xyz_gradient_accum.numpy().copy(), m.denom.numpy().copy()
+            with torch.no_grad():
+                m.xyz_gradient_accum, m.denom = stats["accum"].clone(), stats["denom"].clone()
+                m.max_radii2D = stats["radii"].clone()
+                m.densify_and_prune(0.0002, 0.005, 3.0, max_screen)
+        finally:
+            gm.torch = mgm.torch = GU.torch = torch
+        rec.update(snapshot(m, tag))
+        rec[f"{tag}_z"] = px.draws[0].numpy()                          # the standard-normal draws of the split
+        assert len(px.draws) == 1
+    # ---- prune_points alone: ask for EVERYTHING, then for one of two Gaussians per face ---------------------------------
+    px = _CpuTorch()
+    gm.torch = mgm.torch = GU.torch = px
+    try:
+        with torch.no_grad():
+            m = prepared(px)
+            P = faces.shape[0]
+            m.max_radii2D = torch.zeros(P)
+            m.prune_points(torch.ones(P, dtype=torch.bool))
+            rec["pruneall_P"] = np.array(m._xyz.shape[0])
+            rec["pruneall_counter"] = m.binding_counter.numpy().copy()
+            m.percent_dense = 1e9
+            m.densify_and_clone(torch.ones(P, 1), 0.5, 1.0)
+            rec["cloneall_P"], rec["cloneall_counter"] = np.array(m._xyz.shape[0]), m.binding_counter.numpy().copy()
+            mask = torch.zeros(2 * P, dtype=torch.bool)
+            mask[::3] = True                                           # both Gaussians of some faces, one of others, none of the rest
+            m.prune_points(mask)
+            rec["prunesome_mask"] = mask.numpy()
+            rec["prunesome_binding"], rec["prunesome_counter"] = m.binding.numpy().copy(), m.binding_counter.numpy().copy()
+            rec["prunesome_xyz"] = m._xyz.detach().numpy().copy()
+    finally:
+        gm.torch = mgm.torch = GU.torch = torch
+    np.savez_compressed(os.path.join(OUT, "densify.npz"), **rec)
+
+
+def render_args_golden():
+    """render_args.npz: the reference's render() (gaussian_renderer/__init__.py:21-122) run with a RECORDING rasterizer in
+    place of the extension: which tensors it hands over, in which mode, for the default path, the s3 selection (pc.shs,
+    get_final_xyz, vis_mask), the python SH / cov3D paths with a scaling modifier, and override_color."""
+    import types
+    _, _, recmod = _import_reference_models()
+    calls = []
+
+    class Settings(types.SimpleNamespace):
+        pass
+
+    class Rasterizer:
+        def __init__(self, raster_settings):
+            self.rs = raster_settings
+
+        def __call__(self, **kw):
+            calls.append((self.rs, kw))
+            n = kw["means3D"].shape[0]
+            H, W = self.rs.image_height, self.rs.image_width
+            return torch.zeros(3, H, W), torch.arange(n, dtype=torch.int32) % 3, torch.zeros(1, H, W), torch.zeros(1, H, W)
+    recmod.GaussianRasterizationSettings = lambda **kw: Settings(**kw)
+    recmod.GaussianRasterizer = Rasterizer
+    import importlib
+    GR = importlib.import_module("gaussian_renderer")
+    g = torch.Generator().manual_seed(11)
+    P, K = 6, 4
+    fix = dict(_xyz=torch.zeros(P, 3), get_xyz=torch.randn(P, 3, generator=g), get_opacity=torch.rand(P, 1, generator=g),
+               get_scaling=torch.rand(P, 3, generator=g), get_rotation=torch.randn(P, 4, generator=g),
+               get_features=torch.randn(P, K, 3, generator=g), shs=torch.randn(P, K, 3, generator=g),
+               local_xyz=torch.randn(P, 3, generator=g), get_final_xyz=torch.randn(P, 3, generator=g) + 10,
+               override=torch.rand(P, 3, generator=g))
+    cam = types.SimpleNamespace(FoVx=0.9, FoVy=0.7, image_height=48, image_width=64,
+                                world_view_transform=torch.randn(4, 4, generator=g), full_proj_transform=torch.randn(4, 4, generator=g),
+                                camera_center=torch.randn(3, generator=g))
+    mask = torch.tensor([1, 0, 1, 1, 0, 0], dtype=torch.bool)
+    bg = torch.tensor([0.1, 0.2, 0.3])
+
+    def pc(with_shs=False, with_local=False):
+        o = types.SimpleNamespace(_xyz=fix["_xyz"], active_sh_degree=1, max_sh_degree=1, get_xyz=fix["get_xyz"],
+                                  get_opacity=fix["get_opacity"], get_scaling=fix["get_scaling"], get_rotation=fix["get_rotation"],
+                                  get_features=fix["get_features"], get_covariance=lambda mod: torch.full((P, 6), float(mod)))
+        if with_shs:
+            o.shs = fix["shs"]
+        if with_local:
+            o.local_xyz, o.get_final_xyz = fix["local_xyz"], fix["get_final_xyz"]
+        return o
+    NS = types.SimpleNamespace
+    scenarios = {
+        "default": (pc(), NS(debug=False, compute_cov3D_python=False, convert_SHs_python=False), {}),
+        "s3": (pc(True, True), NS(debug=False, compute_cov3D_python=False, convert_SHs_python=False), dict(vis_mask=mask)),
+        "python": (pc(), NS(debug=True, compute_cov3D_python=True, convert_SHs_python=True), dict(scaling_modifier=0.5)),
+        "override": (pc(), NS(debug=False, compute_cov3D_python=False, convert_SHs_python=False), dict(override_color=fix["override"])),
+        "override_masked": (pc(), NS(debug=False, compute_cov3D_python=False, convert_SHs_python=False),
+                            dict(override_color=fix["override"], vis_mask=mask)),
+    }
+    rec = {"fix_" + k: v.numpy() for k, v in fix.items()}
+    rec.update(cam_fov=np.array([cam.FoVx, cam.FoVy]), cam_size=np.array([cam.image_height, cam.image_width]),
+               cam_view=cam.world_view_transform.numpy(), cam_proj=cam.full_proj_transform.numpy(),
+               cam_center=cam.camera_center.numpy(), vis_mask=mask.numpy(), bg=bg.numpy())
+    px = _CpuTorch()
+    GR.torch = px
+    try:
+        for name, (model, pipe, kw) in scenarios.items():
+            out = GR.render(cam, model, pipe, bg, **kw)
+            rs, args = calls[-1]
+            rec[f"{name}_settings"] = np.array([rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.scale_modifier,
+                                                rs.sh_degree, float(rs.prefiltered), float(rs.debug)], dtype=np.float64)
+            assert rs.bg is bg and rs.viewmatrix is cam.world_view_transform and rs.projmatrix is cam.full_proj_transform
+            assert rs.campos is cam.camera_center
+            rec[f"{name}_none"] = np.array(sorted(k for k, v in args.items() if v is None))
+            for k, v in args.items():
+                if v is not None:
+                    rec[f"{name}_arg_{k}"] = v.detach().numpy().copy()
+            rec[f"{name}_out_keys"] = np.array(sorted(out))
+            rec[f"{name}_visibility"] = out["visibility_filter"].numpy()
+            rec[f"{name}_means2D_requires_grad"] = np.array(bool(args["means2D"].requires_grad))
+    finally:
+        GR.torch = torch
+    np.savez(os.path.join(OUT, "render_args.npz"), **rec)
+
+
 if __name__ == "__main__":
     sh_golden(); camera_golden(); face_golden(); loss_golden(); stylegan_golden(); schedule_golden(); cov3d_golden()
+    model_golden(); render_args_golden()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))

@@ -184,3 +184,97 @@ def test_stylegan_oracle_matches_reference_native_paths():
         out = SO.upfirdn2d(inp, torch.tensor(d[f"ufd_{name}_k"]), (ux, uy), (dx, dy), (px0, px1, py0, py1))
         assert out.shape == d[f"ufd_{name}_out"].shape, name
         assert np.allclose(out.numpy(), d[f"ufd_{name}_out"], rtol=1e-5, atol=1e-6), name
+
+
+# ---- host mirrors of the a13 / a1 rows, pinned to the reference's own functions (tests/golden/make_golden.py imports
+# ---- scene/mesh_gaussian_model.py, scene/gaussian_model.py and gaussian_renderer/__init__.py) ------------------------------
+@pytest.mark.parametrize("is_ff", [True, False])
+def test_training_setup_matches_reference(is_ff):
+    """MeshGaussianModel.training_setup (scene/mesh_gaussian_model.py:350-379): parameter groups, their order, learning
+    rates, Adam hyper-parameters, the xyz schedule and the statistics buffers, for the first frame and for later frames."""
+    from types import SimpleNamespace
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    t, d = _load("training_setup.npz"), _load("densify.npz")
+    opt = SimpleNamespace(**{str(k): float(v) for k, v in zip(t["opt_keys"], t["opt_vals"])})
+    opt.position_lr_max_steps = int(opt.position_lr_max_steps)
+    params = {k: torch.tensor(d["p" + k]) for k in ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")}
+    params["binding"] = torch.arange(d["faces"].shape[0])
+    m = MeshGaussianModel.from_tensors(torch.tensor(d["verts"]), torch.tensor(d["faces"]), params, sh_degree=1, device="cpu")
+    m.training_setup(opt, is_ff=is_ff, optimizer="torch")
+    tag = "ff" if is_ff else "mesh"
+    groups = m.optimizer.param_groups
+    assert isinstance(m.optimizer, torch.optim.Adam)
+    assert [g["name"] for g in groups] == [str(n) for n in t[f"{tag}_names"]]
+    assert np.array_equal(np.array([g["lr"] for g in groups]), t[f"{tag}_lr"])
+    assert np.array_equal(np.array([g["eps"] for g in groups]), t[f"{tag}_eps"])
+    assert np.array_equal(np.array([g["betas"] for g in groups]), t[f"{tag}_betas"])
+    assert [g["params"][0].numel() for g in groups] == list(t[f"{tag}_numel"])
+    assert np.array_equal(np.array([m.xyz_scheduler_args(i) for i in (0, 1, 100, 7000, 30000)]), t[f"{tag}_xyz_lr_at"])
+    assert m.percent_dense == float(t[f"{tag}_percent_dense"])
+    assert [*m.xyz_gradient_accum.shape, *m.denom.shape] == list(t[f"{tag}_stats_shapes"])
+
+
+_RENDER_SCENARIOS = {
+    "default": (dict(), dict(debug=False, compute_cov3D_python=False, convert_SHs_python=False), False, False),
+    "s3": (dict(vis_mask=True), dict(debug=False, compute_cov3D_python=False, convert_SHs_python=False), True, True),
+    "python": (dict(scaling_modifier=0.5), dict(debug=True, compute_cov3D_python=True, convert_SHs_python=True), False, False),
+    "override": (dict(override_color=True), dict(debug=False, compute_cov3D_python=False, convert_SHs_python=False), False, False),
+    "override_masked": (dict(override_color=True, vis_mask=True),
+                        dict(debug=False, compute_cov3D_python=False, convert_SHs_python=False), False, False),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_RENDER_SCENARIOS))
+def test_render_hands_the_rasterizer_what_the_reference_hands_it(name, monkeypatch):
+    """ggsplat.render.render against a RECORDING of the reference's render() (gaussian_renderer/__init__.py:21-122) run with a
+    recording rasterizer in the extension's place: the settings, which arguments are None, and every tensor argument, for
+    the default path, the s3 selection (pc.shs, get_final_xyz, vis_mask), the python SH / cov3D paths with a scaling
+    modifier, and override_color with and without a mask."""
+    from types import SimpleNamespace as NS
+    from ggsplat import render as RM
+    r = _load("render_args.npz")
+    calls = []
+
+    def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):
+        calls.append((settings, dict(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
+                                     opacities=opacities, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)))
+        n, H, W = means3D.shape[0], settings.image_height, settings.image_width
+        return torch.zeros(3, H, W), torch.arange(n, dtype=torch.int32) % 3, torch.zeros(1, H, W), torch.zeros(1, H, W)
+    monkeypatch.setattr(RM, "rasterize_gaussians", rasterize)
+    fix = {k[4:]: torch.tensor(r[k]) for k in r.files if k.startswith("fix_")}
+    P = fix["_xyz"].shape[0]
+    kw, pipe, with_shs, with_local = _RENDER_SCENARIOS[name]
+    pc = NS(_xyz=fix["_xyz"], active_sh_degree=1, max_sh_degree=1, get_xyz=fix["get_xyz"], get_opacity=fix["get_opacity"],
+            get_scaling=fix["get_scaling"], get_rotation=fix["get_rotation"], get_features=fix["get_features"],
+            get_covariance=lambda mod: torch.full((P, 6), float(mod)))
+    if with_shs:
+        pc.shs = fix["shs"]
+    if with_local:
+        pc.local_xyz, pc.get_final_xyz = fix["local_xyz"], fix["get_final_xyz"]
+    cam = NS(FoVx=float(r["cam_fov"][0]), FoVy=float(r["cam_fov"][1]), image_height=int(r["cam_size"][0]),
+             image_width=int(r["cam_size"][1]), world_view_transform=torch.tensor(r["cam_view"]),
+             full_proj_transform=torch.tensor(r["cam_proj"]), camera_center=torch.tensor(r["cam_center"]))
+    kw = dict(kw)
+    if kw.get("vis_mask"):
+        kw["vis_mask"] = torch.tensor(r["vis_mask"])
+    if kw.get("override_color"):
+        kw["override_color"] = fix["override"]
+    bg = torch.tensor(r["bg"])
+    out = RM.render(cam, pc, NS(**pipe), bg, **kw)
+    rs, args = calls[-1]
+    got = np.array([rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.sh_degree,
+                    float(rs.prefiltered), float(rs.debug)], dtype=np.float64)
+    assert np.array_equal(got, r[f"{name}_settings"])
+    assert rs.bg is bg and rs.viewmatrix is cam.world_view_transform and rs.projmatrix is cam.full_proj_transform
+    assert rs.campos is cam.camera_center
+    assert sorted(k for k, v in args.items() if v is None) == [str(k) for k in r[f"{name}_none"]]
+    for k, v in args.items():
+        if v is not None:
+            ref = r[f"{name}_arg_{k}"]
+            assert tuple(v.shape) == ref.shape, k
+            assert np.allclose(v.detach().numpy(), ref, rtol=1e-6, atol=1e-7), k
+    assert bool(args["means2D"].requires_grad) == bool(r[f"{name}_means2D_requires_grad"])
+    # the reference's keys + "tile_count" (the list lengths of THIS forward for the region-of-interest loss)
+    assert sorted(set(out) - {"tile_count"}) == [str(k) for k in r[f"{name}_out_keys"]]
+    assert np.array_equal(out["visibility_filter"].numpy(), r[f"{name}_visibility"])
+    assert out["viewspace_points"].shape == (P, 3) and out["viewspace_points"].requires_grad

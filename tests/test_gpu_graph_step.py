@@ -369,3 +369,42 @@ def test_training_setup_default_is_graph_adam_with_state_dict_round_trip():
         assert torch.equal(pa, pb)
         if pa.numel():                              # _features_rest is empty at SH degree 0
             assert float((pa - pt).abs().max()) <= 2e-6 * float(pt.abs().max()) + 1e-9
+
+
+def test_graph_adam_and_torch_adam_exchange_state_dicts():
+    """a checkpoint written with one optimiser class loads into the other and training continues the same way
+    (torch.optim.Adam -> GraphAdam, GraphAdam -> torch.optim.Adam), within the 2e-6 the two updates agree to."""
+    from ggsplat.adam import GraphAdam
+    gen = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(257, 3), (64, 1, 3), (1000,)]
+    init = [torch.randn(s, device="cuda", generator=gen) for s in shapes]
+    grads = [[torch.randn(s, device="cuda", generator=gen) * 1e-2 for s in shapes] for _ in range(6)]
+
+    def make(kind):
+        ps = [torch.nn.Parameter(t.clone()) for t in init]
+        groups = [{"params": [p], "lr": 1e-3 * (i + 1), "name": f"g{i}"} for i, p in enumerate(ps)]
+        return ps, (GraphAdam(groups, lr=0.0, eps=1e-15) if kind == "graph" else torch.optim.Adam(groups, lr=0.0, eps=1e-15))
+
+    def run(ps, opt, gs):
+        for g in gs:
+            for p, gi in zip(ps, g):
+                p.grad = gi.clone()
+            opt.step()
+            opt.zero_grad()
+    ref_p, ref_o = make("torch")
+    run(ref_p, ref_o, grads)                                   # six torch steps: the reference trajectory
+    for first, second in (("torch", "graph"), ("graph", "torch")):
+        pa, oa = make(first)
+        run(pa, oa, grads[:3])
+        pb, ob = make(second)
+        with torch.no_grad():
+            for b, a in zip(pb, pa):
+                b.copy_(a)
+        ob.load_state_dict(oa.state_dict())
+        run(pb, ob, grads[3:])
+        for b, r in zip(pb, ref_p):
+            assert float((b.detach() - r.detach()).abs().max()) <= 2e-6 * float(r.detach().abs().max()) + 1e-9, (first, second)
+    bad = ref_o.state_dict()
+    bad["param_groups"][0]["amsgrad"] = True
+    with pytest.raises(ValueError, match="amsgrad"):
+        make("graph")[1].load_state_dict(bad)

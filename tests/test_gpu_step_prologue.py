@@ -91,11 +91,12 @@ def test_preclear_marks_are_consumed_once_and_dropped_by_the_next_prologue():
     ref = loss_sums()                                     # no mark: the call clears the sums itself
     assert float(ref[0]) > 0 and float(ref[0]) < 3 * H * W
 
-    def prologue(marked):
+    def prologue(marked, has_consumer=True):
         pro = GgsStepPrologue()
         if marked:
             pro.n_clear = 1
             pro.clear_ptr[0], pro.clear_bytes[0] = sums.data_ptr(), 8
+            pro.consumer_mask = 1 if has_consumer else 0
         check(L.ggs_step_prologue(C.byref(pro), _stream()), "ggs_step_prologue")
 
     prologue(True)
@@ -118,6 +119,24 @@ def test_preclear_marks_are_consumed_once_and_dropped_by_the_next_prologue():
     torch.cuda.current_stream().wait_stream(side)
     assert torch.allclose(got, ref, rtol=1e-6)
     prologue(False)
+    # a range the caller did not flag as having a consumer is cleared but NOT marked (dL/dvertices)
+    prologue(True, has_consumer=False)
+    assert not bool(sums.any())
+    sums.fill_(10.0)
+    assert torch.allclose(loss_sums(), ref, rtol=1e-6)
+    # marks end with the step: ggs_step_end() ...
+    prologue(True)
+    check(L.ggs_step_end(), "ggs_step_end")
+    sums.fill_(10.0)
+    assert torch.allclose(loss_sums(), ref, rtol=1e-6)
+    # ... and ggs_registration_aux*, the step's last consumer, drops what is left (here: a mark it does not consume itself)
+    prologue(True)
+    P = 64
+    radii = torch.ones(P, dtype=torch.int32, device="cuda")
+    check(L.ggs_registration_aux(P, None, None, ptr(radii), None, None, None, None, 0.0, 0.0, 0.0, 0.0, None, None, None, None,
+                                 None, None, None, None, _stream()), "ggs_registration_aux")
+    sums.fill_(10.0)
+    assert torch.allclose(loss_sums(), ref, rtol=1e-6)
 
 
 def test_step_clear_plan_names_what_forward_and_backward_clear():

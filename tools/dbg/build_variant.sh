@@ -11,6 +11,9 @@ mkdir -p $TMP/gaussian-garments_amd/csrc $TMP/include
 cp $SRC/*.hip $SRC/*.h $SRC/Makefile $TMP/gaussian-garments_amd/csrc/
 cp $ROOT/include/*.h $TMP/include/
 F=${VARIANT_FILE:-ggs_render.hip}
+# PATCHES="tools/dbg/variants/x.patch ...": unified diffs (paths relative to the repo root) applied to the scratch copy first --
+# the round-4 reduction variants and what-if branches live there, outside the product translation unit
+for pf in $PATCHES; do (cd $TMP && patch -p0 -s < $ROOT/$pf) || { echo "patch $pf failed"; exit 1; }; done
 if [ $# -gt 0 ]; then sed -i "$@" $TMP/gaussian-garments_amd/csrc/$F; fi
 make -C $TMP/gaussian-garments_amd/csrc -j8 RENDER_EXTRA="$RENDER_EXTRA" PERGAUSS_EXTRA="$PERGAUSS_EXTRA" ALL_EXTRA="$ALL_EXTRA" > $TMP/build.log 2>&1 || { tail -30 $TMP/build.log; exit 1; }
 mkdir -p $SRC/variants

@@ -6,7 +6,7 @@
 # BENCH_ARGS (extra bench.py flags for `ab`).  seltests: TESTS = the selection.
 cd "${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
 export TMPDIR=/tmp
-TAG=${TAG:-r04}
+TAG=${TAG:-r05}
 OUT=gpurun_out
 mkdir -p $OUT
 VAR=gaussian-garments_amd/csrc/variants
@@ -41,6 +41,16 @@ import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_
     timeloss)        # fused photometric loss, us per 1080p view, for each variant library (LIBS) or the product (LIBS=product)
       for f in $( [ "$LIBS" = product ] && echo gaussian-garments_amd/csrc/libggsplat.so || libs ); do echo "--- $f"; for i in 1 2; do GGS_LIB_PATH=$PWD/$f timeout 300 python tools/dbg/time_loss.py 2>&1 | grep "^V="; done; done > $OUT/${TAG}_timeloss.txt; cat $OUT/${TAG}_timeloss.txt ;;
     autograd_floor)  timeout 300 python tools/dbg/autograd_floor.py > $OUT/${TAG}_autograd_floor.txt 2>&1; cat $OUT/${TAG}_autograd_floor.txt ;;
+    pipesweep)       # serial vs two-stream pipelined step over launch-set sizes + the 20-view rank step (tools/dbg/pipeline_sweep.py)
+      timeout 1500 python tools/dbg/pipeline_sweep.py ${REPS:-2} "$SEL" > $OUT/${TAG}_pipeline_sweep.txt 2>&1; cat $OUT/${TAG}_pipeline_sweep.txt ;;
+    pipetrace)       # kernel trace of the serial and the pipelined step: which kernels were in flight together (tools/overlap_summary.py)
+      R=$PWD; for mode in ${MODES:-0 1}; do
+        (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d $R/$OUT/pt$mode -o p -- python $R/bench.py --cpu-views 0 --loop-views 0 --extra-configs 0 --steps 4 --warmup 2 --timing-only --chunk ${CHUNK:-40} --pipeline $mode $BENCH_ARGS > $R/$OUT/pt$mode.log 2>&1)
+        { echo "## --pipeline $mode --chunk ${CHUNK:-40} $BENCH_ARGS (last ${LAST_MS:-40} ms of the trace)"; echo; python tools/overlap_summary.py $(find $OUT/pt$mode -name "*.db" | head -1) --last-ms ${LAST_MS:-40}; echo; grep -h '^{' $OUT/pt$mode.log | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('bench line under the tracer:', d['value'], 'views/s,', d['ms_per_step'], 'ms per step')"; echo; } >> $OUT/${TAG}_pipeline_overlap.md 2>&1
+        rm -rf $OUT/pt$mode; done; cat $OUT/${TAG}_pipeline_overlap.md ;;
+    timefwd)         # forward-only kernel times per view for each variant library (tools/dbg/time_fwd.py): prices the background stores
+      for i in 1 2; do for f in $(libs); do GGS_LIB_PATH=$PWD/$f timeout 300 python tools/dbg/time_fwd.py ${VIEWS:-40} 2>&1 | tail -1; done; done > $OUT/${TAG}_timefwd.txt; cat $OUT/${TAG}_timefwd.txt ;;
+    knn)             timeout 300 python tools/dbg/time_knn.py > $OUT/${TAG}_knn.txt 2>&1; tail -2 $OUT/${TAG}_knn.txt ;;
     bench)           timeout 900 python bench.py $BENCH_ARGS > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; cat $OUT/${TAG}_bench.json ;;
     *) echo "unknown step $step" ;;
   esac
