@@ -36,6 +36,11 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: 8 TB/s HBM3E peak
+N_SIMD, CLOCK_GHZ = 1024, 2.4   # 256 CUs x 4 SIMDs; peak engine clock
+# Average issue cycles per VALU wave-instruction of the compositing kernels' inner loops: the static instruction mix of
+# tools/isa_audit.py (profiles/rNN_isa_audit.md) priced with the measured rates of profiles/r02_valu_issue_rates.md (fma / mul / add
+# 2.8, other VALU 4.3, exp / rcp 8.3): backward quadrant body 27 + 4 + 2 instructions = 110 cycles, reduction block 7 + 9 = 58.
+VALU_CYCLES_PER_INST = {"render_bwd": 3.4, "render_fwd": 3.6}
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: f32 vector (= f32-input MFMA) peak, 256 CUs x 4 SIMDs x 64 FLOP/clk x 2.4 GHz
 # Useful floating-point operations per blended (Gaussian, pixel) pair, counted from the kernels' source (an fma = 2, exp / rcp = 1):
 #   forward  (ggs_render.hip render_fwd_body): dx, dy 2 | exponent 3 mul + 2 fma 7 | exp2 1 | opacity * G 1 | min 1 | alpha * T 1 |
@@ -116,7 +121,7 @@ def extra_config(name, dev, *, sh_degree, n_around, n_rows, W, H, views, chunk, 
                       opacities=model.get_opacity.detach(), shs=model.get_features.detach())
 
     def step():
-        return batch.fwd_bwd_views(inputs, cams, bg=bg, W=W, H=H, sh_degree=sh_degree, chunk=chunk,
+        return batch.fwd_bwd_views(inputs, cams, bg=bg, W=W, H=H, sh_degree=sh_degree, chunk=chunk, want_means2D=True,
                                    dL_dcolor_fn=lambda v0, v1, color: dL[:v1 - v0])
     gr = step()
     torch.cuda.synchronize(dev)
@@ -137,7 +142,7 @@ def extra_config(name, dev, *, sh_degree, n_around, n_rows, W, H, views, chunk, 
     buf = (C.c_float * 8)()
     L.ggs_profile_read(buf, 8)
     fwd_ms = list(buf)[:5]
-    R.backward_views(st, dL[:chunk], want_means2D=False)
+    R.backward_views(st, dL[:chunk], want_means2D=True)
     L.ggs_profile_read(buf, 8)
     L.ggs_profile_enable(0)
     ms = dict(zip(KERNELS, fwd_ms + list(buf)[5:7] + [buf[7]]))
@@ -357,7 +362,7 @@ def main():
             L.ggs_profile_read(buf, 8)
             fwd_ms = list(buf)[:5]
             order_ms = buf[7]
-            R.backward_views(st, dL_buf[:chunk], want_means2D=False)
+            R.backward_views(st, dL_buf[:chunk], want_means2D=bool(args.means2d))
             L.ggs_profile_read(buf, 8)
             ms = fwd_ms + list(buf)[5:7] + [order_ms]
             acc_ms = [a + b for a, b in zip(acc_ms, ms)]
@@ -409,9 +414,19 @@ def main():
                 vj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 if vj.get("build_id") == bid and vj.get("workload") == {"P": Fn, "W": W, "H": H, "sh_degree": args.sh_degree}:
                     kv = vj["kernels"]["ggs_k_" + dom + ("_sh%d" % args.sh_degree if dom == "preprocess_bwd" else "")]
-                    valu = {"busy_pct": round(kv.get("rocprof_valu_busy_pct") or kv["valu_busy_pct"], 1),
+                    valu = {"rocprof_VALUBusy_pct": round(kv.get("rocprof_valu_busy_pct") or kv["valu_busy_pct"], 1),
                             "lane_activity_pct": round(kv.get("rocprof_lane_activity_pct") or kv["lane_activity_pct"], 1),
                             "source": "profiles/" + fn}
+                    valu["busy_pct"] = valu["rocprof_VALUBusy_pct"]     # (key kept for readers of earlier rounds' lines)
+                    # issue utilisation: SQ_INSTS_VALU of the launch x the kernel's average issue cycles per instruction /
+                    # (SIMDs x clock x THIS run's kernel time) -- rocprofv3's derived VALUBusy reads > 100 % on this part
+                    # (VERDICT r4), this figure cannot
+                    cyc = VALU_CYCLES_PER_INST.get(dom)
+                    if cyc and kv.get("valu_insts_per_launch"):
+                        insts = kv["valu_insts_per_launch"] / vj["views_per_launch"] * chunk
+                        valu["insts_per_wave_note"] = "SQ_INSTS_VALU (wave-instructions) of the committed collection, scaled to this launch"
+                        valu["issue_cycles_per_inst"] = cyc
+                        valu["issue_util"] = round(insts * cyc / (N_SIMD * CLOCK_GHZ * 1e9 * group_ms[dom] * 1e-3), 4)
                     break
             except Exception:
                 continue
@@ -430,8 +445,20 @@ def main():
                        "lanes_useful_pct": None if valu is None else valu["lane_activity_pct"],
                        "note": "blended (Gaussian, pixel) pairs from ggs_count_blends; flops per pair counted from the kernel source"}
         bound = "valu" if ((valu is not None and valu["busy_pct"] > 90.0) or (valu is None and flops_pair is not None)) else "hbm"
+        # the two halves of the line: per-kernel HIP-event times x launches per step against the measured step.  The events
+        # bracket every kernel of an EAGER launch set (record + wait around each one), which reads 2-4 % longer than the same
+        # kernels inside the replayed graph: in a rocprofv3 trace of this command the GPU is busy 99.6 % of the step and the
+        # kernel durations sum to the step (profiles/r05_pipeline_overlap.md, --pipeline 0) -- nothing overlaps, nothing idles
+        launches = -(-len(my) // chunk)
+        ksum = sum(kern_ms.values()) * launches
         roofline = {"bound": bound, "kernel": "ggs_k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                    # counter bytes / kernel time / peak: what the HBM pipe actually carries while the dominant kernel runs
+                    "traffic_frac": None if traffic is None else round(traffic / (group_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "kernel_sum_ms_per_step": round(ksum, 3), "launches_per_step": launches,
+                    "step_over_kernel_sum": round(dt / args.steps * 1e3 / ksum, 4),
+                    "kernel_sum_note": "event-bracketed eager kernels x launches per step (mesh binding and the 3 zero fills not "
+                                       "included); < 1: the graph-replayed step is shorter than the sum of its event-timed kernels",
                     "traffic_source": traffic_src if traffic is not None else
                     f"none: no profiles/*_hbm_traffic.json was collected from build {bid} on this workload",
                     "valu": valu, "compute": compute, "launch_views": chunk, "launch_ms": round(group_ms[dom], 4),

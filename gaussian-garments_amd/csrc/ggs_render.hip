@@ -321,6 +321,7 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
     a.out_alpha[(size_t)v * HW + pix] = A;
 }
 
+
 }  // namespace
 
 // K4b: grid V*T work items (x4 for the per-quadrant variant), block 64.

@@ -20,7 +20,12 @@ from simple_knn._C import distCUDA2  # noqa: E402
 
 
 def timed(fn, reps=20):
-    fn(); torch.cuda.synchronize()
+    # three untimed calls: the first call after a host-only stretch finds the GPU at idle clocks (brute-force 3-NN: 7.0 ms for
+    # the first call, 4.2 for calls 2-5, 4.06 steady -- tools/dbg/time_knn.py; r04_next_rows.md quoted 13.4 ms from one warm-up call
+    # and five timed ones behind the mesh construction on the host: a measurement artefact, the kernel had not changed)
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
@@ -61,7 +66,7 @@ def main():
     v, f = S.skirt_mesh()
     P = f.shape[0]
     pts = v[f].mean(1).to(dev)
-    t = timed(lambda: distCUDA2(pts, brute_force=True), reps=5)
+    t = timed(lambda: distCUDA2(pts, brute_force=True), reps=20)
     tf = 8.0 * P * P / t / 1e12
     print(f"| f2 | distCUDA2, exact 3-NN, brute force ({P} face centres of the skirt) | {P}^2 pairs | {t*1e3:.3f} | {tf:.1f} TFLOP/s fp32 | 157.3 TFLOP/s fp32 vector | {tf/1.573:.1f} |")
     t = timed(lambda: distCUDA2(pts), reps=10)

@@ -50,6 +50,10 @@ import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_
         rm -rf $OUT/pt$mode; done; cat $OUT/${TAG}_pipeline_overlap.md ;;
     timefwd)         # forward-only kernel times per view for each variant library (tools/dbg/time_fwd.py): prices the background stores
       for i in 1 2; do for f in $(libs); do GGS_LIB_PATH=$PWD/$f timeout 300 python tools/dbg/time_fwd.py ${VIEWS:-40} 2>&1 | tail -1; done; done > $OUT/${TAG}_timefwd.txt; cat $OUT/${TAG}_timefwd.txt ;;
+    ec)              # two-wave (evaluator / compositor) latency kernels: parity first (short timeouts: a barrier bug hangs), then A/B timing
+      { timeout 400 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_parity.py -x -q 2>&1 | tail -6
+        for ec in 0 1 0 1; do echo -n "GGS_QUAD_EC=$ec "; GGS_QUAD_EC=$ec timeout 200 python tools/dbg/time_fwd.py 1 20 2>&1 | tail -1; done
+        for ec in 0 1 0 1; do echo -n "GGS_QUAD_EC=$ec "; GGS_QUAD_EC=$ec timeout 300 python tools/profile_graph_step.py 256 2>&1 | tail -1; done; } > $OUT/${TAG}_ec.txt 2>&1; cat $OUT/${TAG}_ec.txt ;;
     knn)             timeout 300 python tools/dbg/time_knn.py > $OUT/${TAG}_knn.txt 2>&1; tail -2 $OUT/${TAG}_knn.txt ;;
     bench)           timeout 900 python bench.py $BENCH_ARGS > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; cat $OUT/${TAG}_bench.json ;;
     *) echo "unknown step $step" ;;
