@@ -473,7 +473,7 @@ def main():
                                    "frac": round(B_view * views_per_sec / 1e9 / HBM_PEAK_GBS, 5)}}
 
         # ---- per-view drop-in loop (render() + autograd, one camera per call like the reference) ----
-        loop_vps = step_vps = graph_vps = s3_vps = None
+        loop_vps = step_vps = graph_vps = pipe_vps = s3_vps = None
         if args.loop_views > 0 and world == 1:
             from ggsplat.render import render
             from types import SimpleNamespace
@@ -538,6 +538,16 @@ def main():
             graph_vps = rate(gsteps, len(lcams))
             graph_recaptures = gstep.recaptures
             del gstep
+            # the same iteration, two captured copies replayed alternately and the result of iteration i read while iteration
+            # i + 1 runs (PipelinedRegistrationStep): the host's share of the period no longer idles the GPU
+            from ggsplat.inner_step import PipelinedRegistrationStep
+            pstep = PipelinedRegistrationStep(model, W, H, bg)
+            def psteps():
+                for c, gt_i in zip(lcams, gts):
+                    pstep(c, gt_i, gt_mask)
+                pstep.flush()
+            pipe_vps = rate(psteps, len(lcams))
+            del pstep
             model.optimizer = None
 
             # the s3 iteration in its config-4 form (s3_appearance.py:107-149): texel-bound Gaussians (barycentric origins),
@@ -686,6 +696,8 @@ def main():
             "per_view_loop_views_per_sec": None if loop_vps is None else round(loop_vps, 2),
             "s2_inner_step_iters_per_sec": None if step_vps is None else round(step_vps, 2),
             "s2_graph_step_iters_per_sec": None if graph_vps is None else round(graph_vps, 2),
+            # two captured copies replayed alternately, each result read one iteration late (ggsplat.inner_step.PipelinedRegistrationStep)
+            "s2_pipelined_graph_step_iters_per_sec": None if pipe_vps is None else round(pipe_vps, 2),
             # config-4 FORM of the s3 iteration (texel-bound Gaussians, K = 16, vis mask, five-term loss, Adam) with a two-tensor
             # stand-in for the StyleUNet: a rasterizer + loss + optimiser number, not a config-4 number
             "s3_graph_step_standin_net_iters_per_sec": None if s3_vps is None else round(s3_vps, 2),

@@ -448,16 +448,42 @@ class GraphedRegistrationStep:
     def _same_tensors(a, b) -> bool:
         return a is not None and len(a) == len(b) and all(x is y for x, y in zip(a, b))
 
-    def __call__(self, cam, gt_image, mask=None) -> Dict[str, torch.Tensor]:
-        """One optimisation step.  Returns {"loss", "img", "ssim", ...}: Python floats (lean) or device scalars that the
-        next call overwrites (lean=False)."""
-        self._load(cam, gt_image, mask)
+    def _ready_graph(self):
         if self.graph is not None and not self._same_tensors(self._captured, self._identity()):
             self.graph = None                       # P changed under the graph (densify / prune): capture the new shapes
             self.recaptures += 1
         if self.graph is None:
             self._capture()
-            # the capture itself does not execute anything: fall through to the first replay
+            # the capture itself does not execute anything: the caller replays
+
+    # ---- split form of __call__ for PipelinedRegistrationStep: queue an iteration / read its result later -----------------
+    def launch(self, cam, gt_image, mask=None) -> None:
+        """Queue one iteration on the current stream WITHOUT waiting for it: parameter block, graph replay, result read-back
+        (in place when the result block is mapped pinned memory), an event behind them.  collect() reads the result."""
+        self._last_args = (cam, gt_image, mask)
+        self._load(cam, gt_image, mask)
+        self._ready_graph()
+        self.graph.replay()
+        if not self._out_map:
+            self._out_host.copy_(self._out, non_blocking=True)
+        if getattr(self, "_done", None) is None:
+            self._done = torch.cuda.Event()
+        self._done.record()
+
+    def collect(self):
+        """Wait for the iteration queued by launch().  Returns its loss dictionary, or None when its forward overflowed the
+        static binning capacity (nothing was updated: guarded kernels) -- the caller re-runs it."""
+        self._done.synchronize()
+        self._keep = None
+        if int(self._hdr_host[1]) != 0:
+            return None
+        return self._losses_from_stats() if self.lean else self.out
+
+    def __call__(self, cam, gt_image, mask=None) -> Dict[str, torch.Tensor]:
+        """One optimisation step.  Returns {"loss", "img", "ssim", ...}: Python floats (lean) or device scalars that the
+        next call overwrites (lean=False)."""
+        self._load(cam, gt_image, mask)
+        self._ready_graph()
         while True:
             self.graph.replay()
             if not self._out_map:
@@ -471,6 +497,75 @@ class GraphedRegistrationStep:
             self.recaptures += 1
             self.graph = None
             self._capture()
+
+
+class PipelinedRegistrationStep:
+    """Two captured copies of the lean s2 iteration (GraphedRegistrationStep) replayed ALTERNATELY on one stream, the result of
+    iteration i read while iteration i + 1 runs.
+
+    A replayed iteration is ~0.35 ms of kernels; a caller that waits for each result before it queues the next iteration leaves
+    the GPU idle for the host's share of the period -- writing the 176-byte parameter block, hipGraphLaunch, waking up from the
+    wait, reading the 48-byte result (~20-35 us per iteration).  Here iteration i + 1 is queued BEFORE the host
+    waits for iteration i: the stream runs the two graphs back to back (parameters, optimiser state and statistics are shared:
+    same addresses in both captures, so iteration i + 1 sees the update of iteration i), and every call returns the losses of the
+    PREVIOUS call (None for the first; flush() returns the last).  Two captures because each reads its per-iteration block
+    (camera, image pointers) from its own pinned host block in place: the host may fill block B while the GPU still reads A.
+
+    The reference's loop uses the loss only for its progress bar (s2_registration.py:284-292), so the one-iteration lag costs
+    nothing there.  What differs from the sequential form: an iteration whose forward overflowed the static binning capacity
+    (it changed nothing: guarded kernels) is re-run AFTER the iteration that was already queued behind it -- the two updates
+    swap places.  That happens at most a few times per run (the capacity doubles each time)."""
+
+    def __init__(self, gaussians, W: int, H: int, bg, **kw):
+        kw["lean"] = True
+        self.steps = [GraphedRegistrationStep(gaussians, W, H, bg, **kw) for _ in range(2)]
+        self._pending: Optional[GraphedRegistrationStep] = None
+        self._n = 0
+
+    @property
+    def recaptures(self) -> int:
+        return sum(s.recaptures for s in self.steps)
+
+    def _recover(self, first: GraphedRegistrationStep, second: Optional[GraphedRegistrationStep]) -> Dict[str, float]:
+        """`first` overflowed.  Drain the stream, grow the capacity, drop both captures, re-run `first` (and `second` if it
+        overflowed too) through the sequential form, which re-captures and retries until the capacity fits."""
+        second_ok = None if second is None else second.collect()
+        torch.cuda.synchronize()
+        R.grow_capacity(2.0)
+        for s in self.steps:
+            s.graph = None
+            s.recaptures += 1
+        out = first(*first._last_args)
+        if second is not None and second_ok is None:
+            second_ok = second(*second._last_args)
+        self._late = second_ok           # the result of the iteration queued behind the overflowed one
+        return out
+
+    def __call__(self, cam, gt_image, mask=None) -> Optional[Dict[str, float]]:
+        """Queue iteration n; return the losses of iteration n - 1 (None for n = 0)."""
+        cur = self.steps[self._n & 1]
+        self._n += 1
+        ready, self._ready = getattr(self, "_ready", None), None
+        prev, self._pending = self._pending, cur
+        cur.launch(cam, gt_image, mask)
+        if prev is None:
+            return ready                 # (a result the recovery below already collected, or None for the first call)
+        out = prev.collect()
+        if out is None:                  # iteration n - 1 overflowed: recover both, nothing is pending afterwards
+            out = self._recover(prev, cur)
+            self._pending, self._ready = None, self._late
+        return out
+
+    def flush(self) -> Optional[Dict[str, float]]:
+        """Wait for the last queued iteration and return its losses (None if there is none)."""
+        cur, self._pending = self._pending, None
+        if cur is None:
+            out, self._ready = getattr(self, "_ready", None), None
+            return out
+        out = cur.collect()
+        if out is None:
+            out = self._recover(cur, None)
+        return out
 
 
 class GraphedAppearanceStep(GraphedRegistrationStep):

@@ -4,6 +4,8 @@ registration_step with torch's Adam on the same cameras -- parameters, moments-d
 statistics and loss terms after several iterations."""
 from types import SimpleNamespace
 
+import math
+
 import pytest
 import torch
 
@@ -408,3 +410,58 @@ def test_graph_adam_and_torch_adam_exchange_state_dicts():
     bad["param_groups"][0]["amsgrad"] = True
     with pytest.raises(ValueError, match="amsgrad"):
         make("graph")[1].load_state_dict(bad)
+
+
+@pytest.mark.parametrize("slack", [1.0, 0.002])
+def test_pipelined_registration_step_matches_the_sequential_replay(slack):
+    """PipelinedRegistrationStep: two captured copies of the lean iteration replayed alternately, results read one iteration
+    late.  Same kernels in the same order on one stream as GraphedRegistrationStep -> the same losses (shifted by one call) and
+    the same parameters after N iterations, up to the order of the float atomics of the render backward.  slack 0.002: each
+    capture runs with a binning capacity far too small (as in test_graphed_registration_step_matches_eager), every view overflows its first replay -> the recovery path (re-capture, re-run)."""
+    from ggsplat.inner_step import GraphedRegistrationStep, PipelinedRegistrationStep
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    from ggsplat.inner_step import DEFAULT_OPT
+    v, f, params, cams, gts, masks = _scene(seed=2)
+    W_, H_ = cams[0].image_width, cams[0].image_height
+    bg = torch.zeros(3, device="cuda")
+
+    def model():
+        m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
+        m.training_setup(DEFAULT_OPT, is_ff=True)
+        return m
+    from ggsplat import rasterizer as R
+    a, b = model(), model()
+    R._cap_hint.clear()
+    seq = GraphedRegistrationStep(a, W_, H_, bg)
+    pip = PipelinedRegistrationStep(b, W_, H_, bg, capacity_slack=slack)
+    n = 7
+    ref, got = [], []
+    for i in range(n):
+        c, gt, mk = cams[i % len(cams)], gts[i % len(cams)], masks[i % len(cams)]
+        ref.append(seq(c, gt, mk))
+        r = pip(c, gt, mk)
+        if i == 0:
+            assert r is None
+        else:
+            got.append(r)
+    got.append(pip.flush())
+    assert pip.flush() is None and len(got) == n
+    if slack == 1.0:
+        assert pip.recaptures == 0
+        for r, g_ in zip(ref, got):               # the same iteration, read one call later
+            assert abs(r["loss"] - g_["loss"]) <= 1e-5 * abs(r["loss"]) + 1e-7
+    else:
+        assert pip.recaptures >= 2 and all(math.isfinite(g_["loss"]) for g_ in got)
+    # Same kernels on both sides; the float atomics of the render backward add in another order, and Adam with eps 1e-15 turns
+    # a gradient whose sign is decided by that noise into a full +-lr step (see test_graphed_registration_step_matches_eager):
+    # 99.5 % of every tensor within tolerance.  With overflows an iteration is re-run behind its successor: only a small mean
+    # deviation is required.
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        if not pa.numel():
+            continue
+        x, y = pb.detach(), pa.detach()
+        if slack == 1.0:
+            ok = (x - y).abs() <= 2e-6 + 1e-4 * y.abs()
+            assert float(ok.float().mean()) >= 0.995 and float((x - y).abs().mean()) <= 1e-5
+        else:
+            assert float((x - y).abs().mean()) <= 5e-3 and bool(torch.isfinite(x).all())

@@ -27,14 +27,24 @@ with torch.no_grad():
     m.update_face_coor()
     gts = [(render(c, m, pipe, bg)["render"] + 0.02 * torch.randn(3, H, W, device=dev)).clamp(0, 1).contiguous() for c in cams]
 mask = (torch.rand(1, H, W, device=dev) > 0.1).float()
-step = GraphedRegistrationStep(m, W, H, bg)
+pipelined = "--pipelined" in sys.argv
+if pipelined:
+    from ggsplat.inner_step import PipelinedRegistrationStep
+    sys.argv.remove("--pipelined")
+    step = PipelinedRegistrationStep(m, W, H, bg)
+else:
+    step = GraphedRegistrationStep(m, W, H, bg)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 for i in range(2):
     step(cams[i], gts[i], mask)
+if pipelined:
+    step.flush()
 torch.cuda.synchronize()
 t = time.perf_counter()
 for i in range(n):
     step(cams[i % len(cams)], gts[i % len(cams)], mask)
+if pipelined:
+    step.flush()
 torch.cuda.synchronize()
 dt = time.perf_counter() - t
-print(f"graphed s2 step: {n/dt:.1f} it/s, {dt/n*1e3:.3f} ms/it, recaptures {step.recaptures}")
+print(f"{'pipelined (two captures, results one iteration late)' if pipelined else 'graphed'} s2 step: {n/dt:.1f} it/s, {dt/n*1e3:.3f} ms/it, recaptures {step.recaptures}")
