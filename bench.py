@@ -70,9 +70,13 @@ def parse():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every step eagerly instead of replaying the captured hipGraph of its compute part")
-    ap.add_argument("--pipeline", type=int, default=0,
-                    help="1: the backward of launch set i on a second stream beside the forward of set i + 1 (ggsplat.batch "
-                         "fwd_bwd_views(pipeline=True): two parallel branches in the captured graph)")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="launch sets software-pipelined over a second stream (ggsplat.batch.fwd_bwd_views(pipeline=...): parallel "
+                         "branches in the captured graph).  1 (default): the backward of set i beside the whole forward of set "
+                         "i + 1 -- the render kernels do not overlap (the forward's 256-thread kernels are starved until the "
+                         "backward drains), but the small kernels and the launch gaps of one chain hide under the other: "
+                         "+0.6 ... +1.7 %% on three boxes; 2: only the compositing beside the backward (-1 %%); 0: serial "
+                         "(profiles/r05_pipeline_overlap.md, r05_pipeline_sweep.txt)")
     ap.add_argument("--means2d", type=int, default=1,
                     help="1: the timed step also returns dL/dmeans2D of every view (an output of the reference's backward, a5; "
                          "the densification statistics read it)")
@@ -100,7 +104,7 @@ def alg_bytes(P, K, P_vis, N, HW, T):
     }
 
 
-def extra_config(name, dev, *, sh_degree, n_around, n_rows, W, H, views, chunk, steps):
+def extra_config(name, dev, *, sh_degree, n_around, n_rows, W, H, views, chunk, steps, pipeline=0):
     """One more workload of the same hot path, timed the same way (fwd+bwd of `views` views per step through the batched
     entry points, eager launches) and priced against the same roofline: the K = 16 variant of config 2 and the stress
     config 5 of BASELINE.json.  Returns the extra keys of the JSON line."""
@@ -122,7 +126,7 @@ def extra_config(name, dev, *, sh_degree, n_around, n_rows, W, H, views, chunk, 
 
     def step():
         return batch.fwd_bwd_views(inputs, cams, bg=bg, W=W, H=H, sh_degree=sh_degree, chunk=chunk, want_means2D=True,
-                                   dL_dcolor_fn=lambda v0, v1, color: dL[:v1 - v0])
+                                   pipeline=pipeline, dL_dcolor_fn=lambda v0, v1, color: dL[:v1 - v0])
     gr = step()
     torch.cuda.synchronize(dev)
     best = float("inf")
@@ -154,7 +158,7 @@ def extra_config(name, dev, *, sh_degree, n_around, n_rows, W, H, views, chunk, 
     dom_gbs = B[dom] * chunk / (ms[dom] * 1e-3) / 1e9
     B_view = sum(B.values())
     return {"workload": f"{name}: {Fn} mesh-bound Gaussians, {W}x{H}, SH degree {sh_degree}, {views} views per step, "
-                        f"{chunk} per launch, eager launches, better of two timed passes of {steps} steps", "value": round(vps, 2), "unit": "views/s",
+                        f"{chunk} per launch, eager launches{' (launch sets pipelined over two streams)' if pipeline else ''}, better of two timed passes of {steps} steps", "value": round(vps, 2), "unit": "views/s",
             "num_rendered_per_view": round(N_view, 1),
             "roofline": {"kernel": "ggs_k_" + dom, "achieved": round(dom_gbs, 2), "frac": round(dom_gbs / HBM_PEAK_GBS, 5),
                          "kernel_ms_per_launch": {k: round(v, 4) for k, v in ms.items()},
@@ -283,7 +287,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    step()                                   # eager priming (untimed): learns the binning capacity
+    try:
+        step()                               # eager priming (untimed): learns the binning capacity
+    except Exception as e:                   # a second stream that misbehaves must not cost the line: serial launch sets
+        if not args.pipeline:
+            raise
+        print(f"[bench] pipelined launch sets failed ({type(e).__name__}: {e}); running them serially", file=sys.stderr, flush=True)
+        args.pipeline = 0
+        torch.cuda.synchronize(dev)
+        step()
     if not args.no_graph:
         torch.cuda.synchronize(dev)
         capture()
@@ -668,11 +680,11 @@ def main():
                     extras[key] = {"error": f"{type(e).__name__}: {e}"}
                 torch.cuda.empty_cache()
             extra("config2_sh3", "config 2 with SH degree 3 (the s3 setting)", dev, sh_degree=3, n_around=200, n_rows=250, W=1920,
-                  H=1080, views=64, chunk=32, steps=4)
+                  H=1080, views=64, chunk=32, steps=4, pipeline=int(args.pipeline))
             if args.loop_views > 0 and s3net_vps is not None:
                 extras["config4_s3_with_network"] = {"workload": s3net_desc, "value": round(s3net_vps, 2), "unit": "iterations/s"}
             extra("config5_stress", "config 5 (stress)", dev, sh_degree=3, n_around=500, n_rows=500, W=3840, H=2160, views=32,
-                  chunk=16, steps=3)
+                  chunk=16, steps=3, pipeline=int(args.pipeline))
 
         out = {
             "metric": "fwd+bwd views/sec @1080p, 100k mesh-Gaussians",
@@ -682,6 +694,7 @@ def main():
             "config": {"workload": f"{Fn} mesh-bound Gaussians (skirt tube, MeshGaussianModel), {len(all_cams)} synthetic "
                                    f"{W}x{H} cameras, SH degree {args.sh_degree}, fwd+bwd with dense dL/dimage",
                        "views_per_step": n_views_total, "views_per_launch": chunk, "parallelism": f"views sharded x{world}",
+                       "launch_set_pipeline": int(args.pipeline) if len(my) > chunk else 0, "returns_dL_dmeans2D": bool(args.means2d),
                        "backend": ("rccl" if args.backend == "nccl" else args.backend) if world > 1 else None,
                        # gradient exchange: slices per rank (1 = one all-reduce behind the compute); with one rank there is no
                        # collective and no scaling curve in this line

@@ -8,25 +8,25 @@ import sys
 
 BASE = [sys.executable, "bench.py", "--cpu-views", "0", "--loop-views", "0", "--extra-configs", "0", "--warmup", "5", "--timing-only"]
 CONFIGS = [
-    ("160v chunk80 serial  m2d0", ["--steps", "60", "--chunk", "80", "--means2d", "0"]),
-    ("160v chunk80 serial  m2d1", ["--steps", "60", "--chunk", "80"]),
+    ("160v chunk80 serial  m2d0", ["--steps", "60", "--chunk", "80", "--means2d", "0", "--pipeline", "0"]),
+    ("160v chunk80 serial  m2d1", ["--steps", "60", "--chunk", "80", "--pipeline", "0"]),
     ("160v chunk80 piped       ", ["--steps", "60", "--chunk", "80", "--pipeline", "1"]),
-    ("160v chunk40 serial      ", ["--steps", "60", "--chunk", "40"]),
+    ("160v chunk40 serial      ", ["--steps", "60", "--chunk", "40", "--pipeline", "0"]),
     ("160v chunk40 piped       ", ["--steps", "60", "--chunk", "40", "--pipeline", "1"]),
     ("160v chunk40 staged      ", ["--steps", "60", "--chunk", "40", "--pipeline", "2"]),
     ("160v chunk20 staged      ", ["--steps", "60", "--chunk", "20", "--pipeline", "2"]),
     ("160v chunk32 piped       ", ["--steps", "60", "--chunk", "32", "--pipeline", "1"]),
-    ("160v chunk20 serial      ", ["--steps", "60", "--chunk", "20"]),
+    ("160v chunk20 serial      ", ["--steps", "60", "--chunk", "20", "--pipeline", "0"]),
     ("160v chunk20 piped       ", ["--steps", "60", "--chunk", "20", "--pipeline", "1"]),
     ("160v chunk16 piped       ", ["--steps", "60", "--chunk", "16", "--pipeline", "1"]),
     ("160v chunk10 piped       ", ["--steps", "60", "--chunk", "10", "--pipeline", "1"]),
     ("160v chunk40 piped eager ", ["--steps", "60", "--chunk", "40", "--pipeline", "1", "--no-graph"]),
-    ("160v chunk40 serial eager", ["--steps", "60", "--chunk", "40", "--no-graph"]),
-    ("rank: 20v chunk20 serial ", ["--steps", "300", "--views", "20", "--chunk", "20"]),
-    ("rank: 20v chunk10 serial ", ["--steps", "300", "--views", "20", "--chunk", "10"]),
+    ("160v chunk40 serial eager", ["--steps", "60", "--chunk", "40", "--no-graph", "--pipeline", "0"]),
+    ("rank: 20v chunk20 serial ", ["--steps", "300", "--views", "20", "--chunk", "20", "--pipeline", "0"]),
+    ("rank: 20v chunk10 serial ", ["--steps", "300", "--views", "20", "--chunk", "10", "--pipeline", "0"]),
     ("rank: 20v chunk10 piped  ", ["--steps", "300", "--views", "20", "--chunk", "10", "--pipeline", "1"]),
     ("rank: 20v chunk5  piped  ", ["--steps", "300", "--views", "20", "--chunk", "5", "--pipeline", "1"]),
-    ("rank: 20v overlap 2      ", ["--steps", "300", "--views", "20", "--chunk", "10", "--overlap", "2"]),
+    ("rank: 20v overlap 2      ", ["--steps", "300", "--views", "20", "--chunk", "10", "--overlap", "2", "--pipeline", "0"]),
 ]
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 sel = sys.argv[2] if len(sys.argv) > 2 else ""

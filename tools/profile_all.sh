@@ -18,7 +18,8 @@ mkdir -p $R/gpurun_out
 PASSES=${PASSES:-trace sq valu fetch write}
 [ -n "$ONLY_TRACE" ] && PASSES=trace
 BENCH="python $R/bench.py --cpu-views 0 --loop-views 0 --extra-configs 0 $*"
-PMC="$BENCH --steps 1 --warmup 0 --views ${PMC_VIEWS:-32}"
+# counters are sampled per dispatch over the whole device: launch sets must NOT overlap on two streams while they are collected
+PMC="$BENCH --pipeline 0 --steps 1 --warmup 0 --views ${PMC_VIEWS:-32}"
 python -c "import sys; sys.path.insert(0, '$R/gaussian-garments_amd'); from ggsplat import _lib; print(_lib.build_id())" > ${OUT}_build_id.txt
 echo "$*" > ${OUT}_args.txt
 pmc_pass() {   # name, counters...

@@ -9,8 +9,10 @@ WORKLOAD="100000 1920 1080 0" bash tools/profile_all.sh ${N}_sh0 --chunk 32
 WORKLOAD="100000 1920 1080 3" PASSES="trace sq valu fetch write" bash tools/profile_all.sh ${N}_sh3 --sh-degree 3 --chunk 32
 WORKLOAD="500000 3840 2160 3" PASSES="trace sq valu fetch write" bash tools/profile_all.sh ${N}_c5 --sh-degree 3 --n-around 500 --n-rows 500 --width 3840 --height 2160 --chunk 16 --views 32
 ONLY_TRACE=1 bash tools/profile_all.sh ${N}_v20 --views 20 --chunk 20
-# the launch shape of the DEFAULT bench line (80 views per launch): the per-launch durations of roofline.launch_ms
+# the launch shape of the DEFAULT bench line (40 views per launch, launch sets pipelined over two streams), and the same with
+# serial launch sets: the per-launch durations of roofline.launch_ms
 ONLY_TRACE=1 bash tools/profile_all.sh ${N}_default
+ONLY_TRACE=1 bash tools/profile_all.sh ${N}_serial --pipeline 0
 WORKLOAD="100000 1920 1080 0" PMC_VIEWS=1 PASSES="trace sq fetch write" bash tools/profile_all.sh ${N}_v1 --views 1 --chunk 1 --no-graph
 # graph-replayed s2 step: where one iteration's GPU time goes
 cd /tmp && export TMPDIR=/tmp
