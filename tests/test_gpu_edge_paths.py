@@ -235,3 +235,42 @@ def test_backward_twice_on_one_forward_gives_the_same_gradients():
             assert float(first["means3D"].abs().sum()) > 0
             for k in first:
                 assert rel_l1(second[k], first[k]) <= 1e-6, (V, k)
+
+
+def test_forward_stages_queued_one_by_one_equal_the_one_call_forward():
+    """ggs_forward_stages (round 5): COUNT, BIN and COMPOSITE queued as three calls (rasterizer.StagedForward) give the outputs,
+    the per-pixel workspace and the sorted lists of the one-call forward bit for bit, a staged forward feeds the backward like any
+    other, and a stage mask that is not a combination of the three stages is an argument error, not a launch."""
+    import ctypes as C
+    from ggsplat import _lib, rasterizer as R
+    sc, cam = small_scene(P=900, W=112, H=80, sh_degree=1, seed=21)
+    dev = "cuda"
+    t = {k: sc[k].to(dev) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    cams = S.stack_cameras([cam, cam], device=dev)
+    kw = dict(view=cams["view"], proj=cams["proj"], campos=cams["campos"], tanfov=cams["tanfov"],
+              bg=torch.tensor([0.1, 0.2, 0.3], device=dev), W=112, H=80, sh_degree=1)
+    color, radii, depth, alpha, st = R.forward_views(t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None, **kw)
+    fwd = R.StagedForward(t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None, **kw)
+    for stage in (fwd.COUNT, fwd.BIN, fwd.COMPOSITE):
+        fwd.run(stage)
+    torch.cuda.synchronize()
+    c2, r2, d2, a2 = fwd.outputs
+    assert torch.equal(c2, color) and torch.equal(r2, radii) and torch.equal(d2, depth) and torch.equal(a2, alpha)
+    assert int(fwd.header[1]) == 0 and int(fwd.header[0]) == st.num_rendered
+    s1, s2 = R.img_sections(st), R.img_sections(fwd.state)
+    assert torch.equal(s1["final_T"], s2["final_T"]) and torch.equal(s1["n_contrib"], s2["n_contrib"])
+    n = st.num_rendered
+    assert torch.equal(R.bin_sections(st)["ids"][:n], R.bin_sections(fwd.state)["ids"][:n])
+    w = torch.randn(2, 3, 80, 112, generator=torch.Generator().manual_seed(4)).to(dev)
+    g1, g2 = R.backward_views(st, w), R.backward_views(fwd.state, w)
+    for k in g1:
+        assert rel_l1(g2[k], g1[k]) <= 2e-6, k
+    L = _lib.lib()
+    for bad in (0, 8, -1, 16 | 1):
+        assert L.ggs_forward_stages(bad, *fwd._args, _lib.stream_ptr(torch.device(dev))) != 0
+        assert b"ggs_forward_stages" in L.ggs_last_error()
+    # a shape that was never run through forward_views has no learnt binning capacity: refused, not guessed
+    R._cap_hint.pop((torch.device(dev).index or 0, 900, 112, 80, 1), None)
+    with pytest.raises(_lib.GgsError, match="forward_views once"):
+        R.StagedForward(t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None,
+                        **{**kw, **{k: v[:1] for k, v in cams.items()}})
