@@ -70,9 +70,9 @@ def parse():
     ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
     ap.add_argument("--no-graph", action="store_true",
                     help="launch every step eagerly instead of replaying the captured hipGraph of its compute part")
-    ap.add_argument("--pipeline", type=int, default=1,
+    ap.add_argument("--pipeline", type=int, default=None,
                     help="launch sets software-pipelined over a second stream (ggsplat.batch.fwd_bwd_views(pipeline=...): parallel "
-                         "branches in the captured graph).  1 (default): the backward of set i beside the whole forward of set "
+                         "branches in the captured graph).  1 (default on one GPU; multi-rank runs default to 0: first-try safe): the backward of set i beside the whole forward of set "
                          "i + 1 -- the render kernels do not overlap (the forward's 256-thread kernels are starved until the "
                          "backward drains), but the small kernels and the launch gaps of one chain hide under the other: "
                          "+0.6 ... +1.7 %% on three boxes; 2: only the compositing beside the backward (-1 %%); 0: serial "
@@ -188,6 +188,8 @@ def main():
         sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.pipeline is None:       # +1 % on one GPU; a multi-rank run (never measured on hardware) keeps the plain serial launch sets
+        args.pipeline = 1 if world == 1 else 0
     if world != args.gpus:
         raise SystemExit(f"bench: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
