@@ -230,7 +230,10 @@ def test_pipelined_fwd_bwd_views_equals_the_serial_form(mode, captured):
     cams = S.stack_cameras(S.rig_cameras(n_rings=2, n_az=5, radius=2.2, width=Wd, height=Hd, f=120.0, seed=4), device="cuda")
     bg = torch.zeros(3, device="cuda")
     dL = torch.randn(10, 3, Hd, Wd, generator=torch.Generator().manual_seed(3)).cuda()
-    fn = lambda v0, v1, color: dL[v0:v1]
+    gt = torch.rand(10, 3, Hd, Wd, generator=torch.Generator().manual_seed(5)).cuda()
+    # the loss gradient DEPENDS on the rendered image (an L2 term on top of a fixed weight image): the pipelined forms must hand
+    # the backward of a launch set the colours of ITS forward, computed on the caller's stream behind that forward
+    fn = lambda v0, v1, color: dL[v0:v1] + 2.0 * (color - gt[v0:v1])
 
     def run(pipeline):
         return batch.model_fwd_bwd_views(m, cams, bg=bg, W=Wd, H=Hd, chunk=3, dL_dcolor_fn=fn, pipeline=pipeline, want_means2D=True)
