@@ -56,6 +56,9 @@ import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_
       { timeout 400 python -m pytest tests/test_gpu_fullsize.py tests/test_gpu_parity.py -x -q 2>&1 | tail -6
         for ec in 0 1 0 1; do echo -n "GGS_QUAD_EC=$ec "; GGS_QUAD_EC=$ec timeout 200 python tools/dbg/time_fwd.py 1 20 2>&1 | tail -1; done
         for ec in 0 1 0 1; do echo -n "GGS_QUAD_EC=$ec "; GGS_QUAD_EC=$ec timeout 300 python tools/profile_graph_step.py 256 2>&1 | tail -1; done; } > $OUT/${TAG}_ec.txt 2>&1; cat $OUT/${TAG}_ec.txt ;;
+    ldspad)          # occupancy cap of the per-quadrant kernels through unused dynamic LDS (GGS_QUAD_LDS_PAD): forward time + graph step
+      for pad in ${PADS:-0 8192 14336 17408 24576 36864}; do echo -n "GGS_QUAD_LDS_PAD=$pad "; GGS_QUAD_LDS_PAD=$pad timeout 200 python tools/dbg/time_fwd.py 1 20 2>&1 | tail -1
+        echo -n "GGS_QUAD_LDS_PAD=$pad "; GGS_QUAD_LDS_PAD=$pad timeout 300 python tools/profile_graph_step.py 256 2>&1 | tail -1; done > $OUT/${TAG}_ldspad.txt 2>&1; cat $OUT/${TAG}_ldspad.txt ;;
     knn)             timeout 300 python tools/dbg/time_knn.py > $OUT/${TAG}_knn.txt 2>&1; tail -2 $OUT/${TAG}_knn.txt ;;
     bench)           timeout 900 python bench.py $BENCH_ARGS > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; cat $OUT/${TAG}_bench.json ;;
     *) echo "unknown step $step" ;;
