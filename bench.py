@@ -681,12 +681,14 @@ def main():
                 except Exception as e:
                     extras[key] = {"error": f"{type(e).__name__}: {e}"}
                 torch.cuda.empty_cache()
+            # one launch set per step for both (profiles/r05_extras_sweep.txt: K = 16 64 views per launch 13.66-13.87k against
+            # 13.44-13.63k at 32 pipelined; config 5 32 views per launch 3.07-3.08k against 3.02-3.03k at 16 pipelined)
             extra("config2_sh3", "config 2 with SH degree 3 (the s3 setting)", dev, sh_degree=3, n_around=200, n_rows=250, W=1920,
-                  H=1080, views=64, chunk=32, steps=4, pipeline=int(args.pipeline))
+                  H=1080, views=64, chunk=64, steps=4, pipeline=int(args.pipeline))
             if args.loop_views > 0 and s3net_vps is not None:
                 extras["config4_s3_with_network"] = {"workload": s3net_desc, "value": round(s3net_vps, 2), "unit": "iterations/s"}
             extra("config5_stress", "config 5 (stress)", dev, sh_degree=3, n_around=500, n_rows=500, W=3840, H=2160, views=32,
-                  chunk=16, steps=3, pipeline=int(args.pipeline))
+                  chunk=32, steps=3, pipeline=int(args.pipeline))
 
         out = {
             "metric": "fwd+bwd views/sec @1080p, 100k mesh-Gaussians",
