@@ -42,8 +42,10 @@ def fwd_bwd_views(inputs: Dict[str, torch.Tensor], cams: Dict[str, torch.Tensor]
     compositing beside it (_fwd_bwd_views_staged).  Both work eagerly and inside a stream capture (the second stream joins the
     capture through the events and is joined back before returning: the captured graph has parallel branches).  Same kernels,
     same order of the backward launches; the results equal the serial form up to the order of the float atomics inside the
-    render backward (run-to-run noise of the serial form itself, ~1e-7).  MEASURED on MI355X (profiles/r05_pipeline_overlap.md):
-    neither form is faster than the serial one -- kept as an option and as the evidence for that statement."""
+    render backward (run-to-run noise of the serial form itself, ~1e-7).  MEASURED on MI355X (profiles/r05_pipeline_overlap.md,
+    r05_pipeline_sweep.txt): with 1 the two render kernels never meet (the forward's 256-thread kernels are starved beside the
+    backward's flood of one-wave workgroups) but launch gaps and small kernels hide under the other chain: +0.6 ... +1.7 %, bench.py's
+    default on one GPU; with 2 the render kernels interleave and take each other's issue slots: -1 %."""
     V = cams["view"].shape[0]
     dev = inputs["means3D"].device
     if int(pipeline) == 2 and V > chunk and dev.type == "cuda" and not keep_images:
