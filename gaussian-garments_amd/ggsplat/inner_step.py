@@ -514,7 +514,9 @@ class PipelinedRegistrationStep:
     The reference's loop uses the loss only for its progress bar (s2_registration.py:284-292), so the one-iteration lag costs
     nothing there.  What differs from the sequential form: an iteration whose forward overflowed the static binning capacity
     (it changed nothing: guarded kernels) is re-run AFTER the iteration that was already queued behind it -- the two updates
-    swap places.  That happens at most a few times per run (the capacity doubles each time)."""
+    swap places.  That happens at most a few times per run (the capacity doubles each time).
+    Density control between two calls needs no flush(): it runs on the same stream behind the queued iteration, and each copy
+    re-captures itself on its next launch when the tensors it captured were replaced (GraphedRegistrationStep._ready_graph)."""
 
     def __init__(self, gaussians, W: int, H: int, bg, **kw):
         kw["lean"] = True
