@@ -223,3 +223,36 @@ def test_captured_step_recaptures_when_density_control_changes_P():
 def _attr(name):
     return {"xyz": "_xyz", "f_dc": "_features_dc", "f_rest": "_features_rest", "opacity": "_opacity", "scaling": "_scaling",
             "rotation": "_rotation"}[name]
+
+
+def test_pipelined_step_survives_density_control_between_calls():
+    """PipelinedRegistrationStep needs no flush() around densify_and_prune: the density step runs on the same stream behind the
+    queued iteration, and each of the two captured copies re-captures itself on its next launch (P changed).  Same final state as
+    the sequential captured step driven through the same calls."""
+    from ggsplat.inner_step import DEFAULT_PIPE, PipelinedRegistrationStep
+    from ggsplat.render import render
+    W, H = 256, 192
+    cams = S.rig_cameras(n_rings=1, n_az=4, width=W, height=H, f=200.0, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    a, b = small_model(graph_adam=True), small_model(graph_adam=True)
+    with torch.no_grad():
+        gts = [render(c, a, DEFAULT_PIPE, bg)["render"].clone() for c in cams]
+    mask = torch.ones(1, H, W, device=DEV)
+    seq, pip = GraphedRegistrationStep(a, W, H, bg), PipelinedRegistrationStep(b, W, H, bg)
+    out_seq, out_pip = [], []
+    for i in range(8):
+        if i == 4:                                    # density control in the middle, with an iteration of `pip` still in flight
+            torch.manual_seed(5); a.densify_and_prune(1e-7, 0.005, 1.0, None)
+            torch.manual_seed(5); b.densify_and_prune(1e-7, 0.005, 1.0, None)
+        out_seq.append(seq(cams[i % 4], gts[i % 4], mask))
+        r = pip(cams[i % 4], gts[i % 4], mask)
+        if r is not None:
+            out_pip.append(r)
+    out_pip.append(pip.flush())
+    assert len(out_pip) == 8 and seq.recaptures == 1 and pip.recaptures == 2
+    assert a._xyz.shape[0] == b._xyz.shape[0] != 2000
+    for x, y in zip(out_seq, out_pip):
+        assert math.isfinite(y["loss"]) and abs(x["loss"] - y["loss"]) <= 1e-3 * abs(x["loss"]) + 1e-6
+    for n in ("_xyz", "_scaling", "_opacity", "_features_dc"):
+        p, q = getattr(a, n).detach(), getattr(b, n).detach()
+        assert float((p - q).abs().mean()) <= 1e-4, n
