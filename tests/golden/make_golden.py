@@ -411,6 +411,31 @@ def model_golden():
         rec.update(snapshot(m, tag))
         rec[f"{tag}_z"] = px.draws[0].numpy()                          # the standard-normal draws of the split
         assert len(px.draws) == 1
+    # ---- the getters, reset_opacity, update_learning_rate, get_covariance of the reference model on the prepared state ----------
+    px = _CpuTorch()
+    gm.torch = mgm.torch = GU.torch = px
+    try:
+        with torch.no_grad():
+            m = prepared(px)
+            # get_xyz / get_scaling (scene/mesh_gaussian_model.py:105-128; get_rotation needs roma, which this image lacks)
+            rec["get_xyz"], rec["get_scaling"] = m.get_xyz.numpy().copy(), m.get_scaling.numpy().copy()
+            rec["get_opacity"], rec["get_features"] = m.get_opacity.numpy().copy(), m.get_features.numpy().copy()
+            rec["face_center"], rec["face_scaling"] = m.face_center.numpy().copy(), m.face_scaling.numpy().copy()
+            # get_covariance(scaling_modifier): the LOCAL rotation with the mesh-bound scaling (scene/gaussian_model.py:118-119)
+            rec["get_covariance_1p5"] = m.get_covariance(1.5).numpy().copy()
+            # update_learning_rate (scene/gaussian_model.py:171-177): the "xyz" group only
+            rec["lr_iters"] = np.array([1, 500, 7000, 30000])
+            rec["lr_values"] = np.array([m.update_learning_rate(int(i)) for i in rec["lr_iters"]], dtype=np.float64)
+            rec["lr_groups_after"] = np.array([g["lr"] for g in m.optimizer.param_groups], dtype=np.float64)
+            # reset_opacity (scene/gaussian_model.py:212-215, :261-274): clamp at 0.01, zero moments of the opacity group
+            m.reset_opacity()
+            rec["reset_opacity"] = m._opacity.detach().numpy().copy()
+            st = m.optimizer.state[m._opacity]
+            rec["reset_opacity_m1"], rec["reset_opacity_m2"] = st["exp_avg"].numpy().copy(), st["exp_avg_sq"].numpy().copy()
+            other = m.optimizer.state[m._scaling]
+            rec["reset_other_m1_absmax"] = np.array(float(other["exp_avg"].abs().max()))
+    finally:
+        gm.torch = mgm.torch = GU.torch = torch
     # ---- prune_points alone: ask for EVERYTHING, then for one of two Gaussians per face ---------------------------------
     px = _CpuTorch()
     gm.torch = mgm.torch = GU.torch = px
