@@ -537,6 +537,26 @@ def render_args_golden():
             rec[f"{name}_out_keys"] = np.array(sorted(out))
             rec[f"{name}_visibility"] = out["visibility_filter"].numpy()
             rec[f"{name}_means2D_requires_grad"] = np.array(bool(args["means2D"].requires_grad))
+        # doll_render (gaussian_renderer/__init__.py:124-221): attribute names xyz / opacity / scaling / rotation / features,
+        # override_shs, returns (image, depth, alpha)
+        doll = types.SimpleNamespace(xyz=fix["get_xyz"], opacity=fix["get_opacity"], scaling=fix["get_scaling"],
+                                     rotation=fix["get_rotation"], features=fix["get_features"], active_sh_degree=1, max_sh_degree=1,
+                                     covariance=lambda mod: torch.full((P, 6), float(mod)))
+        plain = NS(debug=False, compute_cov3D_python=False, convert_SHs_python=False)
+        doll_scenarios = {"doll_default": {}, "doll_override_shs": dict(override_shs=fix["shs"]),
+                          "doll_override_color": dict(override_color=fix["override"]),
+                          "doll_masked": dict(override_shs=fix["shs"], vis_mask=mask)}
+        for name, kw in doll_scenarios.items():
+            out = GR.doll_render(cam, doll, plain, bg, **kw)
+            rs, args = calls[-1]
+            rec[f"{name}_settings"] = np.array([rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.scale_modifier,
+                                                rs.sh_degree, float(rs.prefiltered), float(rs.debug)], dtype=np.float64)
+            rec[f"{name}_none"] = np.array(sorted(k for k, v in args.items() if v is None))
+            for k, v in args.items():
+                if v is not None:
+                    rec[f"{name}_arg_{k}"] = v.detach().numpy().copy()
+            rec[f"{name}_n_outputs"] = np.array(len(out))
+            rec[f"{name}_out_shapes"] = np.array([list(o.shape) for o in out])
     finally:
         GR.torch = torch
     np.savez(os.path.join(OUT, "render_args.npz"), **rec)

@@ -278,3 +278,40 @@ def test_render_hands_the_rasterizer_what_the_reference_hands_it(name, monkeypat
     assert sorted(set(out) - {"tile_count"}) == [str(k) for k in r[f"{name}_out_keys"]]
     assert np.array_equal(out["visibility_filter"].numpy(), r[f"{name}_visibility"])
     assert out["viewspace_points"].shape == (P, 3) and out["viewspace_points"].requires_grad
+
+
+@pytest.mark.parametrize("name", ["doll_default", "doll_override_shs", "doll_override_color", "doll_masked"])
+def test_doll_render_hands_the_rasterizer_what_the_reference_hands_it(name, monkeypatch):
+    """ggsplat.render.doll_render (row a2) against a recording of the reference's doll_render (gaussian_renderer/__init__.py:
+    124-221): settings, which arguments are None, every tensor argument; (image, depth, alpha) comes back."""
+    from types import SimpleNamespace as NS
+    from ggsplat import render as RM
+    r = _load("render_args.npz")
+    calls = []
+
+    def rasterize(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp, settings):
+        calls.append((settings, dict(means3D=means3D, means2D=means2D, shs=shs, colors_precomp=colors_precomp,
+                                     opacities=opacities, scales=scales, rotations=rotations, cov3D_precomp=cov3D_precomp)))
+        n, H, W = means3D.shape[0], settings.image_height, settings.image_width
+        return torch.zeros(3, H, W), torch.arange(n, dtype=torch.int32) % 3, torch.zeros(1, H, W), torch.zeros(1, H, W)
+    monkeypatch.setattr(RM, "rasterize_gaussians", rasterize)
+    fix = {k[4:]: torch.tensor(r[k]) for k in r.files if k.startswith("fix_")}
+    doll = NS(xyz=fix["get_xyz"], opacity=fix["get_opacity"], scaling=fix["get_scaling"], rotation=fix["get_rotation"],
+              features=fix["get_features"], active_sh_degree=1, max_sh_degree=1)
+    cam = NS(FoVx=float(r["cam_fov"][0]), FoVy=float(r["cam_fov"][1]), image_height=int(r["cam_size"][0]),
+             image_width=int(r["cam_size"][1]), world_view_transform=torch.tensor(r["cam_view"]),
+             full_proj_transform=torch.tensor(r["cam_proj"]), camera_center=torch.tensor(r["cam_center"]))
+    kw = {"doll_default": {}, "doll_override_shs": dict(override_shs=fix["shs"]),
+          "doll_override_color": dict(override_color=fix["override"]),
+          "doll_masked": dict(override_shs=fix["shs"], vis_mask=torch.tensor(r["vis_mask"]))}[name]
+    out = RM.doll_render(cam, doll, NS(debug=False, compute_cov3D_python=False, convert_SHs_python=False), torch.tensor(r["bg"]), **kw)
+    rs, args = calls[-1]
+    got = np.array([rs.image_height, rs.image_width, rs.tanfovx, rs.tanfovy, rs.scale_modifier, rs.sh_degree,
+                    float(rs.prefiltered), float(rs.debug)], dtype=np.float64)
+    assert np.array_equal(got, r[f"{name}_settings"])
+    assert sorted(k for k, v in args.items() if v is None) == [str(k) for k in r[f"{name}_none"]]
+    for k, v in args.items():
+        if v is not None:
+            ref = r[f"{name}_arg_{k}"]
+            assert tuple(v.shape) == ref.shape and np.allclose(v.detach().numpy(), ref, rtol=1e-6, atol=1e-7), k
+    assert len(out) == int(r[f"{name}_n_outputs"]) and [list(o.shape) for o in out] == r[f"{name}_out_shapes"].tolist()
