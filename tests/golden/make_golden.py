@@ -461,6 +461,38 @@ def model_golden():
     np.savez_compressed(os.path.join(OUT, "densify.npz"), **rec)
 
 
+def avatar_golden():
+    """avatar.npz (row a9): AvatarGaussianModel.get_barycentric_3d / get_xyz / get_final_xyz (scene/avatar_gaussian_model.py:
+    140-159) -- the texel-bound model of stage 3, whose origin on the face is a barycentric point instead of the face centre --
+    run on a seeded fixture with several Gaussians per face."""
+    import importlib
+    import types
+    gm, mgm, _ = _import_reference_models()
+    agm = importlib.import_module("scene.avatar_gaussian_model")
+    verts, faces, prm, _, _ = _densify_fixture(seed=3)
+    g = torch.Generator().manual_seed(33)
+    Fn = faces.shape[0]
+    P = 2500
+    binding = torch.randint(0, Fn, (P,), generator=g)
+    bc = torch.rand(P, 3, generator=g) + 0.05
+    bc = bc / bc.sum(1, keepdim=True)
+    local = torch.randn(P, 3, generator=g) * 0.05
+    final_local = local + torch.randn(P, 3, generator=g) * 0.01
+    m = object.__new__(agm.AvatarGaussianModel)
+    gm.GaussianModel.__init__(m, 3)
+    m.mesh = types.SimpleNamespace(v=verts.clone(), f=faces.clone())
+    m.binding = binding
+    m._xyz, m.local_xyz = local, final_local
+    m._scaling = torch.log(torch.rand(P, 3, generator=g) * 0.6 + 0.25)
+    m.gs_bc = (bc[:, 0], bc[:, 1], bc[:, 2])
+    m.face_center = m.mesh.v[m.mesh.f].mean(1)
+    m.face_orien_mat, m.face_scaling = compute_face_orientation(m.mesh.v, m.mesh.f, return_scale=True)
+    np.savez_compressed(os.path.join(OUT, "avatar.npz"), verts=verts.numpy(), faces=faces.numpy(), binding=binding.numpy(),
+                        gs_bc=bc.numpy(), xyz=local.numpy(), local_xyz=final_local.numpy(), log_scaling=m._scaling.numpy(),
+                        barycentric_3d=m.get_barycentric_3d().numpy(), get_xyz=m.get_xyz.numpy(),
+                        get_final_xyz=m.get_final_xyz.numpy(), get_scaling=m.get_scaling.numpy())
+
+
 def render_args_golden():
     """render_args.npz: the reference's render() (gaussian_renderer/__init__.py:21-122) run with a RECORDING rasterizer in
     place of the extension: which tensors it hands over, in which mode, for the default path, the s3 selection (pc.shs,
@@ -564,5 +596,5 @@ def render_args_golden():
 
 if __name__ == "__main__":
     sh_golden(); camera_golden(); face_golden(); loss_golden(); stylegan_golden(); schedule_golden(); cov3d_golden()
-    model_golden(); render_args_golden()
+    model_golden(); avatar_golden(); render_args_golden()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))
