@@ -493,6 +493,143 @@ def avatar_golden():
                         get_final_xyz=m.get_final_xyz.numpy(), get_scaling=m.get_scaling.numpy())
 
 
+def _loop_body(script, start_marker, end_marker):
+    """The lines of a reference SCRIPT from the first line containing `start_marker` to the first later line containing
+    `end_marker`, dedented: the inner-loop bodies of s2_registration.py / s3_appearance.py are not functions, so they are executed
+    from the file (here only; the text never leaves /root/reference) in a namespace of seeded stand-ins."""
+    import textwrap
+    lines = open(os.path.join(REF, script)).read().splitlines(keepends=True)
+    i0 = next(i for i, l in enumerate(lines) if start_marker in l)
+    i1 = next(i for i in range(i0, len(lines)) if end_marker in lines[i])
+    return textwrap.dedent("".join(lines[i0:i1 + 1])), (i0 + 1, i1 + 1)
+
+
+def _stub_render_arrays(P, H, W, n_feat, seed):
+    g = torch.Generator().manual_seed(seed)
+    return dict(Wc=torch.randn(3 * H * W, n_feat, generator=g) * 0.8, Cv=torch.randn(P, 3, generator=g) * 0.05,
+                radii=(torch.rand(P, generator=g) > 0.2).int() * torch.randint(1, 40, (P,), generator=g).int())
+
+
+def _stub_render(arr, H, W, feats):
+    """A differentiable stand-in for render() shared (as arrays in the golden file) with the tests: the image is a fixed smooth
+    function of a few parameter means + a linear term in the screen-space tensor, radii / visibility are fixed."""
+    def render(viewpoint_cam, gaussians, pipe, bg, **kw):
+        z = torch.cat([f(gaussians).reshape(-1) for f in feats])
+        vsp = torch.zeros_like(gaussians._xyz, requires_grad=True)
+        image = torch.sigmoid(arr["Wc"] @ z).view(3, H, W) * 0.9 + 0.01 * (vsp * arr["Cv"]).sum()
+        radii = arr["radii"]
+        return {"render": image, "viewspace_points": vsp, "visibility_filter": radii > 0, "radii": radii}
+    return render
+
+
+def loop_golden():
+    """loops.npz: ONE iteration of the s2 loop body (s2_registration.py `gaussians.update_face_coor()` ... `optimizer.zero_grad()`)
+    and of the s3 loop body (s3_appearance.py `# predict appearance` ... `avatar_net.optimizer.zero_grad()`) EXECUTED from the
+    reference scripts on the reference's own model classes, with render() / the network replaced by seeded differentiable
+    stand-ins (stored in the file): loss terms, parameters and Adam moments after the step, densification statistics."""
+    import importlib
+    import types
+    NS = types.SimpleNamespace
+    gm, mgm, _ = _import_reference_models()
+    import utils.general_utils as GU
+    import torch.nn.functional as F
+    rec = {}
+    H, W = 24, 32
+    verts, faces, prm, _, _ = _densify_fixture(seed=8)
+    P = faces.shape[0]
+    g = torch.Generator().manual_seed(81)
+    gt, mask = torch.rand(3, H, W, generator=g), (torch.rand(1, H, W, generator=g) > 0.25).float()
+    bg = torch.tensor([0.0, 0.0, 0.0])
+    cam = NS(original_image=NS(cuda=lambda: gt.clone()), gt_alpha_mask=NS(cuda=lambda: mask.clone()))
+    opt = NS(**_OPT, random_background=False, only_foreground_loss=True, lambda_dssim=0.2, threshold_xyz=0.02, lambda_xyz=1e-2,
+             threshold_scale=0.6, lambda_scale=1.0, densify_from_iter=10 ** 9, densification_interval=100,
+             opacity_reset_interval=10 ** 9, densify_grad_threshold=0.0002)
+    rec.update(verts=verts.numpy(), faces=faces.numpy(), gt=gt.numpy(), mask=mask.numpy(), HW=np.array([H, W]),
+               **{"p" + k: v.numpy() for k, v in prm.items()},
+               s2_opt=np.array([opt.lambda_dssim, opt.threshold_xyz, opt.lambda_xyz, opt.threshold_scale, opt.lambda_scale]))
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    # ---- s2 ---------------------------------------------------------------------------------------------------------------
+    feats2 = (lambda m: m._features_dc.mean(0), lambda m: m._opacity.mean(0), lambda m: m._xyz.mean(0), lambda m: m._scaling.mean(0),
+              lambda m: m._rotation.mean(0), lambda m: m.mesh.v.mean(0))
+    arr2 = _stub_render_arrays(P, H, W, 3 + 1 + 3 + 3 + 4 + 3, seed=82)
+    rec.update({"s2_stub_" + k: v.numpy() for k, v in arr2.items()})
+    body, span = _loop_body("s2_registration.py", "gaussians.update_face_coor()", "gaussians.optimizer.zero_grad()")
+    rec["s2_lines"] = np.array(span)
+    px = _CpuTorch()
+    gm.torch = mgm.torch = GU.torch = px
+    try:
+        m = _reference_model(gm, mgm, verts, faces, prm)
+        m.training_setup(opt, True)
+        m.update_face_coor = lambda: None              # (needs roma; the stand-in render does not read the face frames)
+        m.mesh.get_energy_loss = lambda args, use_body=False: {}        # cloth energies: out of scope (SURVEY section 2)
+        m.max_radii2D = torch.zeros(P)
+        ns = dict(gaussians=m, viewpoint_stack=[cam], randint=lambda a, b: 0, scene=NS(getTrainCameras=lambda: [cam], cameras_extent=3.0),
+                  opt=opt, background=bg, pipe=NS(debug=False), render=_stub_render(arr2, H, W, feats2), torch=torch, F=F,
+                  l1_loss=l1_loss, ssim=ssim, is_first_frame=True, args=NS(is_template_seq=True), use_body=False, iter=5,
+                  iterations=100, dataset=NS(white_background=False), iter_end=NS(record=lambda: None))
+        exec(compile(body, "s2_registration.py[loop body]", "exec"), ns)
+    finally:
+        gm.torch = mgm.torch = GU.torch = torch
+    for k in ("img", "ssim", "xyz", "scale"):
+        rec["s2_loss_" + k] = np.array(float(ns["loss_dict"][k]))
+    rec["s2_vsp_grad"] = ns["viewspace_point_tensor"].grad.numpy().copy()
+    for n in names:
+        p_ = getattr(m, n)
+        rec["s2" + n] = p_.detach().numpy().copy()
+        st_ = m.optimizer.state.get(p_, {})               # (a parameter the stand-in image does not depend on gets no gradient, no state)
+        rec["s2" + n + "_m1"] = st_["exp_avg"].numpy().copy() if "exp_avg" in st_ else np.zeros_like(rec["s2" + n])
+    rec["s2_verts"], rec["s2_verts_m1"] = m.mesh.v.detach().numpy().copy(), m.optimizer.state[m.mesh.v]["exp_avg"].numpy().copy()
+    rec["s2_max_radii2D"], rec["s2_accum"], rec["s2_denom"] = m.max_radii2D.numpy().copy(), m.xyz_gradient_accum.numpy().copy(), m.denom.numpy().copy()
+    # ---- s3 ---------------------------------------------------------------------------------------------------------------
+    agm = importlib.import_module("scene.avatar_gaussian_model")
+    K = 4
+    g3 = torch.Generator().manual_seed(83)
+    prm3 = dict(prm)
+    prm3["_features_rest"] = torch.randn(P, K - 1, 3, generator=g3) * 0.1
+    net = dict(xyz_off=torch.randn(P, 3, generator=g3) * 0.01, sh_off=torch.randn(P, K, 3, generator=g3) * 0.03,
+               vis=(torch.rand(P, generator=g3) > 0.4))
+    args3 = NS(only_foreground_loss=True, lambda_dssim=0.2, threshold_xyz=0.02, lambda_xyz=1e-2, threshold_scale=0.6, lambda_scale=1.0,
+               threshold_opacity=0.75, lambda_opacity=0.01)
+    rec.update(s3_features_rest=prm3["_features_rest"].numpy(), s3_net_xyz_off=net["xyz_off"].numpy(), s3_net_sh_off=net["sh_off"].numpy(),
+               s3_net_vis=net["vis"].numpy(),
+               s3_opt=np.array([args3.lambda_dssim, args3.threshold_xyz, args3.lambda_xyz, args3.threshold_scale, args3.lambda_scale,
+                                args3.threshold_opacity, args3.lambda_opacity]))
+    feats3 = (lambda m: m.shs.mean(0).reshape(-1), lambda m: m.get_opacity.mean(0), lambda m: m.local_xyz.mean(0), lambda m: m._scaling.mean(0))
+    arr3 = _stub_render_arrays(P, H, W, 3 * K + 1 + 3 + 3, seed=84)
+    rec.update({"s3_stub_" + k: v.numpy() for k, v in arr3.items()})
+    body3, span3 = _loop_body("s3_appearance.py", "shadow_shs, vis_mask = avatar_net(", "avatar_net.optimizer.zero_grad()")
+    rec["s3_lines"] = np.array(span3)
+    from torch import nn
+    m3 = object.__new__(agm.AvatarGaussianModel)
+    gm.GaussianModel.__init__(m3, 1)
+    for k, v in prm3.items():
+        setattr(m3, k, nn.Parameter(v.clone()))
+    xyz_off, sh_off = nn.Parameter(net["xyz_off"].clone()), nn.Parameter(net["sh_off"].clone())
+
+    class Net:                                          # what AvatarNet.forward leaves behind (scene/avatar_net.py:82-87), no network
+        optimizer = torch.optim.Adam([{"params": [xyz_off], "lr": 1e-4}, {"params": [sh_off], "lr": 2e-3},
+                                      {"params": [m3._opacity], "lr": 1e-2}, {"params": [m3._scaling], "lr": 2e-3},
+                                      {"params": [m3._features_dc], "lr": 2.5e-3}], lr=0.0, eps=1e-15)
+
+        def __call__(self, ambient, normal, camera):
+            m3.local_xyz = m3._xyz + xyz_off
+            m3.shs = m3.get_features + sh_off
+            return sh_off, net["vis"]
+    tens = NS(cuda=lambda: None)
+    ns3 = dict(avatar_net=Net(), frame_data={"ambient": tens, "normal": tens}, viewpoint_cam=cam, gaussians=m3, args=args3, bg=bg,
+               render=_stub_render(arr3, H, W, feats3), torch=torch, F=F, l1_loss=l1_loss, ssim=ssim,
+               logger=lambda *a, **k: None, progress_bar=None, iter=3)
+    # the stand-in render ignores vis_mask (the reference gathers inside render(): gaussian_renderer/__init__.py:92-100); the
+    # loop body itself only passes it through
+    exec(compile(body3, "s3_appearance.py[loop body]", "exec"), ns3)
+    for k in ("img", "ssim", "xyz", "scale", "opacity"):
+        rec["s3_loss_" + k] = np.array(float(ns3["loss_dict"][k]))
+    for n, p_ in (("xyz_off", xyz_off), ("sh_off", sh_off), ("_opacity", m3._opacity), ("_scaling", m3._scaling), ("_features_dc", m3._features_dc)):
+        rec["s3_after_" + n] = p_.detach().numpy().copy()
+        rec["s3_m1_" + n] = Net.optimizer.state[p_]["exp_avg"].numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "loops.npz"), **rec)
+
+
 def render_args_golden():
     """render_args.npz: the reference's render() (gaussian_renderer/__init__.py:21-122) run with a RECORDING rasterizer in
     place of the extension: which tensors it hands over, in which mode, for the default path, the s3 selection (pc.shs,
@@ -596,5 +733,5 @@ def render_args_golden():
 
 if __name__ == "__main__":
     sh_golden(); camera_golden(); face_golden(); loss_golden(); stylegan_golden(); schedule_golden(); cov3d_golden()
-    model_golden(); avatar_golden(); render_args_golden()
+    model_golden(); avatar_golden(); loop_golden(); render_args_golden()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))

@@ -315,3 +315,95 @@ def test_doll_render_hands_the_rasterizer_what_the_reference_hands_it(name, monk
             ref = r[f"{name}_arg_{k}"]
             assert tuple(v.shape) == ref.shape and np.allclose(v.detach().numpy(), ref, rtol=1e-6, atol=1e-7), k
     assert len(out) == int(r[f"{name}_n_outputs"]) and [list(o.shape) for o in out] == r[f"{name}_out_shapes"].tolist()
+
+
+# ---- the inner-loop BODIES of s2_registration.py / s3_appearance.py, executed from the reference scripts (tests/golden/make_golden.py
+# ---- loop_golden) with render() / the network replaced by seeded differentiable stand-ins stored in tests/golden/loops.npz ----------
+def _stub_render(d, tag, feats):
+    H, W = (int(x) for x in d["HW"])
+    Wc, Cv, radii = torch.tensor(d[tag + "_stub_Wc"]), torch.tensor(d[tag + "_stub_Cv"]), torch.tensor(d[tag + "_stub_radii"])
+
+    def render(viewpoint_cam, gaussians, pipe, bg, **kw):
+        z = torch.cat([f(gaussians).reshape(-1) for f in feats])
+        vsp = torch.zeros_like(gaussians._xyz, requires_grad=True)
+        image = torch.sigmoid(Wc @ z).view(3, H, W) * 0.9 + 0.01 * (vsp * Cv).sum()
+        return {"render": image, "viewspace_points": vsp, "visibility_filter": radii > 0, "radii": radii}
+    return render
+
+
+def _mostly_close(a, ref, what):
+    """After ONE Adam step with eps 1e-15 every element moved by +-lr: an element whose gradient is rounding noise may take the
+    other sign in the two implementations -- 99.8 % of a tensor must agree, the rest by no more than two learning rates."""
+    a, ref = a.detach().double(), torch.as_tensor(ref).double()
+    ok = (a - ref).abs() <= 1e-7 + 1e-5 * ref.abs()
+    assert float(ok.double().mean()) >= 0.998, (what, float(ok.double().mean()))
+    assert float((a - ref).abs().max()) <= 0.11, what
+
+
+def test_registration_step_matches_the_reference_loop_body(monkeypatch):
+    """ggsplat.inner_step.registration_step (row a13) against ONE iteration of the loop body of s2_registration.py (lines 238-327 of
+    the reference: update_face_coor ... optimizer.zero_grad()) executed from the script on the reference's own model class: the four
+    loss terms, the screen-space gradient, every parameter and first moment after the Adam step, the densification statistics."""
+    from types import SimpleNamespace as NS
+    from ggsplat import inner_step as IS
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    d, t = _load("loops.npz"), _load("training_setup.npz")
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    params = {k: torch.tensor(d["p" + k]) for k in names}
+    params["binding"] = torch.arange(d["faces"].shape[0])
+    m = MeshGaussianModel.from_tensors(torch.tensor(d["verts"]), torch.tensor(d["faces"]), params, sh_degree=1, device="cpu")
+    o = {str(k): float(v) for k, v in zip(t["opt_keys"], t["opt_vals"])}
+    lam, thr_xyz, lam_xyz, thr_scale, lam_scale = (float(x) for x in d["s2_opt"])
+    opt = NS(**o, lambda_dssim=lam, threshold_xyz=thr_xyz, lambda_xyz=lam_xyz, threshold_scale=thr_scale, lambda_scale=lam_scale,
+             only_foreground_loss=True)
+    opt.position_lr_max_steps = int(opt.position_lr_max_steps)
+    m.training_setup(opt, is_ff=True, optimizer="torch")
+    feats = (lambda g: g._features_dc.mean(0), lambda g: g._opacity.mean(0), lambda g: g._xyz.mean(0), lambda g: g._scaling.mean(0),
+             lambda g: g._rotation.mean(0), lambda g: g.mesh.v.mean(0))
+    monkeypatch.setattr(IS, "render", _stub_render(d, "s2", feats))
+    out = IS.registration_step(m, NS(), torch.tensor(d["gt"]), torch.tensor(d["mask"]), torch.zeros(3), opt=opt,
+                               first_frame_template=True, track_densification=True, fused_loss=False)
+    for k in ("img", "ssim", "xyz", "scale"):
+        assert abs(float(out[k].detach()) - float(d["s2_loss_" + k])) <= 2e-6 * max(1.0, abs(float(d["s2_loss_" + k]))), k
+    assert np.allclose(out["render_pkg"]["viewspace_points"].grad.numpy(), d["s2_vsp_grad"], rtol=1e-4, atol=1e-9)
+    for n in names:
+        _mostly_close(getattr(m, n), d["s2" + n], n)
+        st = m.optimizer.state.get(getattr(m, n), {})
+        m1 = st["exp_avg"] if "exp_avg" in st else torch.zeros_like(getattr(m, n))
+        assert np.allclose(m1.numpy(), d["s2" + n + "_m1"], rtol=1e-4, atol=1e-10), n
+    _mostly_close(m.mesh.v, d["s2_verts"], "mesh.v")
+    assert np.allclose(m.optimizer.state[m.mesh.v]["exp_avg"].numpy(), d["s2_verts_m1"], rtol=1e-4, atol=1e-10)
+    assert np.array_equal(m.max_radii2D.numpy(), d["s2_max_radii2D"]) and np.array_equal(m.denom.numpy(), d["s2_denom"])
+    assert np.allclose(m.xyz_gradient_accum.numpy(), d["s2_accum"], rtol=1e-4, atol=1e-10)
+
+
+def test_appearance_step_matches_the_reference_loop_body(monkeypatch):
+    """ggsplat.inner_step.appearance_step (row a14) against ONE iteration of the loop body of s3_appearance.py (lines 121-147: network
+    call, render(vis_mask), five-term loss, backward, optimiser step) executed from the script on the reference's
+    AvatarGaussianModel, the network replaced by two offset tensors as AvatarNet.forward leaves them (scene/avatar_net.py:82-87)."""
+    from types import SimpleNamespace as NS
+    from ggsplat import inner_step as IS
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    d = _load("loops.npz")
+    names = ("_xyz", "_features_dc", "_opacity", "_scaling", "_rotation")
+    params = {k: torch.tensor(d["p" + k]) for k in names}
+    params["_features_rest"] = torch.tensor(d["s3_features_rest"])
+    params["binding"] = torch.arange(d["faces"].shape[0])
+    m = MeshGaussianModel.from_tensors(torch.tensor(d["verts"]), torch.tensor(d["faces"]), params, sh_degree=1, device="cpu")
+    xyz_off = torch.nn.Parameter(torch.tensor(d["s3_net_xyz_off"]))
+    sh_off = torch.nn.Parameter(torch.tensor(d["s3_net_sh_off"]))
+    vis = torch.tensor(d["s3_net_vis"])
+    optim = torch.optim.Adam([{"params": [xyz_off], "lr": 1e-4}, {"params": [sh_off], "lr": 2e-3}, {"params": [m._opacity], "lr": 1e-2},
+                              {"params": [m._scaling], "lr": 2e-3}, {"params": [m._features_dc], "lr": 2.5e-3}], lr=0.0, eps=1e-15)
+    lam, thr_xyz, lam_xyz, thr_scale, lam_scale, thr_op, lam_op = (float(x) for x in d["s3_opt"])
+    opt = NS(lambda_dssim=lam, threshold_xyz=thr_xyz, lambda_xyz=lam_xyz, threshold_scale=thr_scale, lambda_scale=lam_scale,
+             threshold_opacity=thr_op, lambda_opacity=lam_op, only_foreground_loss=True)
+    feats = (lambda g: g.shs.mean(0).reshape(-1), lambda g: g.get_opacity.mean(0), lambda g: g.local_xyz.mean(0), lambda g: g._scaling.mean(0))
+    monkeypatch.setattr(IS, "render", _stub_render(d, "s3", feats))
+    out = IS.appearance_step(m, lambda g, cam: (xyz_off, sh_off, vis), NS(), torch.tensor(d["gt"]), torch.tensor(d["mask"]),
+                             torch.zeros(3), optimizer=optim, opt=opt, fused_loss=False)
+    for k in ("img", "ssim", "xyz", "scale", "opacity"):
+        assert abs(float(out[k].detach()) - float(d["s3_loss_" + k])) <= 2e-6 * max(1.0, abs(float(d["s3_loss_" + k]))), k
+    for n, p_ in (("xyz_off", xyz_off), ("sh_off", sh_off), ("_opacity", m._opacity), ("_scaling", m._scaling), ("_features_dc", m._features_dc)):
+        _mostly_close(p_, d["s3_after_" + n], n)
+        assert np.allclose(optim.state[p_]["exp_avg"].numpy(), d["s3_m1_" + n], rtol=1e-4, atol=1e-10), n
