@@ -630,6 +630,44 @@ def loop_golden():
     np.savez_compressed(os.path.join(OUT, "loops.npz"), **rec)
 
 
+def ply_golden():
+    """ply_layout.npz (row f2): what the reference's MeshGaussianModel.save_ply(path, save_local=True) hands to plyfile
+    (scene/mesh_gaussian_model.py:251-283, construct_list_of_attributes scene/gaussian_model.py:179-191) -- property order and the
+    per-vertex record -- and the binding.pkl it writes, with and without a `valid_faces` filter.  plyfile is not installed: its
+    stand-in RECORDS the structured array (like the rasterizer stand-in records render()'s arguments); pickle is real."""
+    import pickle
+    import tempfile
+    import types
+    gm, mgm, _ = _import_reference_models()
+    recorded = []
+    ply = sys.modules["plyfile"]
+    ply.PlyElement = types.SimpleNamespace(describe=lambda elements, name: recorded.append((name, elements.copy())) or elements)
+    ply.PlyData = lambda els: types.SimpleNamespace(write=lambda path: None)
+    mgm.PlyElement, mgm.PlyData = ply.PlyElement, ply.PlyData
+    verts, faces, prm, _, _ = _densify_fixture(seed=9)
+    g = torch.Generator().manual_seed(91)
+    P = 300
+    binding = torch.randint(0, 40, (P,), generator=g)
+    prm = {k: v[:P].clone() for k, v in prm.items()}
+    prm["_features_rest"] = torch.randn(P, 3, 3, generator=g) * 0.1
+    rec = {"p" + k: v.numpy() for k, v in prm.items()}
+    rec["binding"] = binding.numpy()
+    for tag, valid in (("all", []), ("valid", [3, 5, 8, 13, 21, 34])):
+        m = _reference_model(gm, mgm, verts, faces, prm)
+        m.binding = binding.clone()
+        m.mesh.valid_faces = valid
+        with tempfile.TemporaryDirectory() as tmp:
+            m.save_ply(os.path.join(tmp, "pc", "local_point_cloud.ply"), save_local=True)
+            with open(os.path.join(tmp, "pc", "binding.pkl"), "rb") as f:
+                rec[f"{tag}_binding_pkl"] = np.asarray(pickle.load(f))
+        name, el = recorded[-1]
+        assert name == "vertex"
+        rec[f"{tag}_names"] = np.array(el.dtype.names)
+        rec[f"{tag}_records"] = np.stack([el[n] for n in el.dtype.names], 1).astype(np.float32)
+    rec["valid_faces"] = np.array([3, 5, 8, 13, 21, 34])
+    np.savez_compressed(os.path.join(OUT, "ply_layout.npz"), **rec)
+
+
 def render_args_golden():
     """render_args.npz: the reference's render() (gaussian_renderer/__init__.py:21-122) run with a RECORDING rasterizer in
     place of the extension: which tensors it hands over, in which mode, for the default path, the s3 selection (pc.shs,
@@ -733,5 +771,5 @@ def render_args_golden():
 
 if __name__ == "__main__":
     sh_golden(); camera_golden(); face_golden(); loss_golden(); stylegan_golden(); schedule_golden(); cov3d_golden()
-    model_golden(); avatar_golden(); loop_golden(); render_args_golden()
+    model_golden(); avatar_golden(); loop_golden(); ply_golden(); render_args_golden()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))

@@ -53,3 +53,33 @@ def test_degree_mismatch_and_ascii(tmp_path):
                    "end_header\n1.5 2.5 7\n-1 0 255\n")
     d = ply_io.read_ply(str(txt))
     assert d["x"].tolist() == [1.5, -1.0] and d["red"].tolist() == [7, 255] and d["red"].dtype == np.uint8
+
+
+@pytest.mark.parametrize("tag", ["all", "valid"])
+def test_save_ply_writes_what_the_reference_hands_to_plyfile(tag, tmp_path):
+    """MeshGaussianModel.save_ply(path, save_local=True) (row f2) against a RECORDING of the reference's own save_ply
+    (scene/mesh_gaussian_model.py:251-283; tests/golden/ply_layout.npz: the structured array it hands to plyfile and the binding.pkl
+    it pickles): property order, every per-vertex record, the binding of the written Gaussians, with and without `valid_faces`."""
+    import os
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    from ggsplat.mesh_io import load_binding
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "ply_layout.npz"))
+    names = ("_xyz", "_features_dc", "_features_rest", "_opacity", "_scaling", "_rotation")
+    params = {k: torch.tensor(d["p" + k]) for k in names}
+    params["binding"] = torch.tensor(d["binding"])
+    P = params["binding"].shape[0]
+    verts = torch.randn(60, 3, generator=torch.Generator().manual_seed(0))
+    faces = torch.randint(0, 60, (40, 3), generator=torch.Generator().manual_seed(1))
+    m = MeshGaussianModel.from_tensors(verts, faces, params, sh_degree=1, device="cpu")
+    if tag == "valid":
+        m.mesh.valid_faces = [int(x) for x in d["valid_faces"]]
+    path = str(tmp_path / "pc" / "local_point_cloud.ply")
+    m.save_ply(path, save_local=True)
+    raw = open(path, "rb").read()
+    head = raw[:raw.index(b"end_header\n")].decode().splitlines()
+    assert [l.split()[-1] for l in head[3:]] == [str(n) for n in d[f"{tag}_names"]]
+    cols = ply_io.read_ply(path)
+    got = np.stack([cols[str(n)] for n in d[f"{tag}_names"]], 1)
+    assert got.shape == d[f"{tag}_records"].shape and np.array_equal(got, d[f"{tag}_records"])
+    assert np.array_equal(load_binding(os.path.join(os.path.dirname(path), "binding.pkl"), device="cpu").numpy(), d[f"{tag}_binding_pkl"])
+    assert got.shape[0] == (P if tag == "all" else int(np.isin(d["binding"], d["valid_faces"]).sum()))
