@@ -668,6 +668,34 @@ def ply_golden():
     np.savez_compressed(os.path.join(OUT, "ply_layout.npz"), **rec)
 
 
+def obj_golden():
+    """obj_io.npz (row f2): the OBJ dialect of utils/io_utils.py:7-60 -- the TEXT the reference's write_obj produces for a mesh with
+    and without texture coordinates (as bytes), and what its read_obj parses from it."""
+    import tempfile
+    import types
+    for name in ("plyfile",):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    if not hasattr(sys.modules["plyfile"], "PlyData"):
+        sys.modules["plyfile"].PlyData = sys.modules["plyfile"].PlyElement = None
+    import importlib
+    io_utils = importlib.import_module("utils.io_utils")
+    g = np.random.default_rng(12)
+    V, Fn, Vt = 37, 50, 44
+    mesh = {"vertices": g.normal(size=(V, 3)).astype(np.float32) * np.float32(1.7), "uvs": g.random((Vt, 2)).astype(np.float32),
+            "faces": g.integers(0, V, (Fn, 3)), "texture_faces": g.integers(0, Vt, (Fn, 3))}
+    rec = {"in_" + k: v for k, v in mesh.items()}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, m in (("uv", mesh), ("plain", {k: mesh[k] for k in ("vertices", "faces")})):
+            path = os.path.join(tmp, tag + ".obj")
+            io_utils.write_obj(m, path)
+            rec[tag + "_text"] = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+            back = io_utils.read_obj(path)
+            for k, v in back.items():
+                rec[f"{tag}_read_{k}"] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, "obj_io.npz"), **rec)
+
+
 def render_args_golden():
     """render_args.npz: the reference's render() (gaussian_renderer/__init__.py:21-122) run with a RECORDING rasterizer in
     place of the extension: which tensors it hands over, in which mode, for the default path, the s3 selection (pc.shs,
@@ -771,5 +799,5 @@ def render_args_golden():
 
 if __name__ == "__main__":
     sh_golden(); camera_golden(); face_golden(); loss_golden(); stylegan_golden(); schedule_golden(); cov3d_golden()
-    model_golden(); avatar_golden(); loop_golden(); ply_golden(); render_args_golden()
+    model_golden(); avatar_golden(); loop_golden(); ply_golden(); obj_golden(); render_args_golden()
     print("wrote", sorted(f for f in os.listdir(OUT) if f.endswith(".npz")))

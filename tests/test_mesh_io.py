@@ -87,3 +87,33 @@ def test_binding_pickle_of_other_writers(tmp_path):
     assert mesh_io.load_binding(path, device="cpu").tolist() == [3, 1, 2]
     pickle.dump([0, 2], open(path, "wb"))
     assert mesh_io.load_binding(path, device="cpu").dtype == torch.int64
+
+
+@pytest.mark.parametrize("tag", ["uv", "plain"])
+def test_obj_dialect_matches_the_reference(tag, tmp_path):
+    """mesh_io.write_obj / read_obj against the reference's own utils/io_utils.py:7-60 (tests/golden/obj_io.npz: the text its
+    write_obj produced and what its read_obj parsed): this repo writes a file the reference parses to the same arrays and parses
+    the reference's file to the arrays the reference parses."""
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "obj_io.npz"))
+    mesh = {k: d["in_" + k] for k in (("vertices", "uvs", "faces", "texture_faces") if tag == "uv" else ("vertices", "faces"))}
+    ref_path = str(tmp_path / "ref.obj")
+    open(ref_path, "wb").write(d[tag + "_text"].tobytes())
+    got = mesh_io.read_obj(ref_path)                                  # the reference's file, this repo's reader
+    for k in ("vertices", "uvs", "faces", "texture_faces"):
+        ref = d[f"{tag}_read_{k}"]
+        assert got[k].shape == ref.shape or (got[k].size == 0 and ref.size == 0), k
+        if ref.size:
+            assert np.array_equal(got[k], ref), k
+    ours = str(tmp_path / "ours.obj")
+    mesh_io.write_obj(mesh, ours)                                     # this repo's file: parses to the same arrays
+    back = mesh_io.read_obj(ours)
+    for k in ("vertices", "uvs", "faces", "texture_faces"):
+        ref = d[f"{tag}_read_{k}"]
+        if ref.size:
+            assert np.array_equal(back[k], ref), k
+    # same statements, same order: v lines, vt lines, f lines with 1-based a/t pairs (float formatting may differ in digits)
+    kinds = lambda p: [l.split()[0] for l in open(p).read().splitlines() if l.strip()]
+    assert kinds(ours) == kinds(ref_path)
+    f_ours = [l for l in open(ours).read().splitlines() if l.startswith("f ")]
+    f_ref = [l for l in open(ref_path).read().splitlines() if l.startswith("f ")]
+    assert f_ours == f_ref
