@@ -348,7 +348,9 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
         a.rec = (SplatRec*)geom; a.aux = (SplatAux*)((char*)geom + ggs_align((size_t)V * p->P * sizeof(SplatRec)));
         a.radii = radii; a.tile_count = tile_count;
         prof_start(K_PRE, s);
-        hipLaunchKernelGGL(ggs_k_preprocess, gridP, dim3(256), 0, s, a);
+        // precomputed colours / SH degree 0 (the s2 setting): the specialisation without the degree 1-3 colour paths
+        if (colors_precomp || p->sh_degree == 0) hipLaunchKernelGGL(ggs_k_preprocess_deg0, gridP, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(ggs_k_preprocess, gridP, dim3(256), 0, s, a);
         prof_stop(K_PRE, s);
         GGS_TRY(check("preprocess", s, p->debug));
     }

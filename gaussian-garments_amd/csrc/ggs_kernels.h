@@ -107,6 +107,7 @@ struct PreBwdArgs {
 };
 
 __global__ void ggs_k_preprocess(PreArgs a);
+__global__ void ggs_k_preprocess_deg0(PreArgs a);
 __global__ void ggs_k_scan_tiles(ScanArgs a);
 __global__ void ggs_k_scatter(ScatterArgs a);
 __global__ void ggs_k_order_tiles(OrderArgs a);

@@ -69,11 +69,12 @@ __device__ __forceinline__ TileWindow block_tile_window(int* s_box, bool has, in
     return w;
 }
 
-}  // namespace
-
-// K1: grid (ceil(P/256), V).  Writes SplatRec + radii, and counts tiles per splat into
-// tile_count[v][t] (cleared by the caller's memset).
-__global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
+// K1 body.  DEG0: the colour comes from precomputed colours or from SH degree 0 only -- the s2 setting and the headline workload.
+// Without the degree 1-3 colour paths the kernel needs 36 instead of 92 VGPRs: eight waves per SIMD instead of five, and this
+// pass is latency-sensitive (profiles/r05_preprocess_div_audit.md: -0.3 us per view at eight waves; forcing the general kernel
+// there spills its degree-3 path).
+template <bool DEG0>
+__device__ __forceinline__ void preprocess_body(const PreArgs& a) {
     __shared__ int s_box[4];
     __shared__ uint32_t s_cnt[BIN_WINDOW_CAP];
     const int g0 = blockIdx.x * 256 + threadIdx.x;
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
                     d[0] = d[0] / len; d[1] = d[1] / len; d[2] = d[2] / len;
                     const float* sh = a.shs + (size_t)g * a.K * 3;
                     float rgb[3];
-                    switch (a.deg) {
+                    if (DEG0) sh_to_rgb<0>(sh, d, rgb, clamped);
+                    else switch (a.deg) {
                         case 0: sh_to_rgb<0>(sh, d, rgb, clamped); break;
                         case 1: sh_to_rgb<1>(sh, d, rgb, clamped); break;
                         case 2: sh_to_rgb<2>(sh, d, rgb, clamped); break;
@@ -207,6 +209,12 @@ __global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) {
     }
     if (has) a.aux[vg].tile_bits = bits;
 }
+
+}  // namespace
+
+// K1: grid (ceil(P/256), V).  Writes SplatRec + radii, and counts tiles per splat into tile_count[v][t] (cleared by the caller).
+__global__ __launch_bounds__(256) void ggs_k_preprocess(PreArgs a) { preprocess_body<false>(a); }
+__global__ __launch_bounds__(256) void ggs_k_preprocess_deg0(PreArgs a) { preprocess_body<true>(a); }
 
 // K3: grid (ceil(P/256), V).  For every (splat, tile) instance take a slot in the tile's
 // segment and write the 64-bit key  depth bits << 32 | id << GGS_NQ | sub-block mask  -- the mask sits BELOW the id so
