@@ -487,7 +487,7 @@ def main():
                                    "frac": round(B_view * views_per_sec / 1e9 / HBM_PEAK_GBS, 5)}}
 
         # ---- per-view drop-in loop (render() + autograd, one camera per call like the reference) ----
-        loop_vps = step_vps = graph_vps = pipe_vps = s3_vps = None
+        loop_vps = step_vps = graph_vps = pipe_vps = s3_vps = sil_vps = sil_frac = None
         if args.loop_views > 0 and world == 1:
             from ggsplat.render import render
             from types import SimpleNamespace
@@ -524,15 +524,19 @@ def main():
             # ground truth of camera i = the INITIAL model's own render of it + a little noise: a registration that starts near its
             # optimum, as a tracked frame does -- against a random image the Gaussians grow iteration by iteration and every
             # later timing would measure a different (heavier) scene
-            def own_renders(mdl, sh_off=None):
+            sil_masks = []        # garment silhouettes of the same cameras (alpha > 0.05): what the data's segmentation masks look like
+            def own_renders(mdl, sh_off=None, silhouettes=None):
                 out = []
                 with torch.no_grad():
                     mdl.update_face_coor()
                     for c in lcams:
-                        img = render(c, mdl, pipe, bg)["render"]
+                        pkg = render(c, mdl, pipe, bg)
+                        img = pkg["render"]
                         out.append((img + 0.02 * torch.randn_like(img)).clamp_(0.0, 1.0).contiguous())
+                        if silhouettes is not None:
+                            silhouettes.append((pkg["alpha"] > 0.05).float().reshape(1, H, W).contiguous())
                 return out
-            gts = own_renders(model)
+            gts = own_renders(model, silhouettes=sil_masks)
             gt_mask = (torch.rand(1, H, W, device=dev) > 0.1).float()
 
             def steps():
@@ -562,6 +566,17 @@ def main():
                 pstep.flush()
             pipe_vps = rate(psteps, len(lcams))
             del pstep
+            # ... and with per-camera SILHOUETTE masks instead of the 90 %-ones one: the captured step then runs the sparse-mask
+            # form of the loss's first pass (ggs_photometric_forward_sparse), which skips the boxes without a mask pixel
+            sstep = PipelinedRegistrationStep(model, W, H, bg)
+            def ssteps():
+                for c, gt_i, m_i in zip(lcams, gts, sil_masks):
+                    sstep(c, gt_i, m_i)
+                sstep.flush()
+            sil_vps = rate(ssteps, len(lcams))
+            sil_frac = float(torch.stack(sil_masks).mean())
+            sil_sparse = bool(sstep.steps[0]._sparse)
+            del sstep
             model.optimizer = None
 
             # the s3 iteration in its config-4 form (s3_appearance.py:107-149): texel-bound Gaussians (barycentric origins),
@@ -715,6 +730,10 @@ def main():
             "s2_graph_step_iters_per_sec": None if graph_vps is None else round(graph_vps, 2),
             # two captured copies replayed alternately, each result read one iteration late (ggsplat.inner_step.PipelinedRegistrationStep)
             "s2_pipelined_graph_step_iters_per_sec": None if pipe_vps is None else round(pipe_vps, 2),
+            # the same, with per-camera garment silhouettes as masks (a segmentation mask; the figures above use a 90 %-ones
+            # salt-and-pepper mask, kept for comparison across rounds): the loss's first pass skips the masked-out boxes
+            "s2_pipelined_graph_step_silhouette_mask": None if sil_vps is None else {
+                "iters_per_sec": round(sil_vps, 2), "mask_ones_frac": round(sil_frac, 4), "sparse_loss_pass": sil_sparse},
             # config-4 FORM of the s3 iteration (texel-bound Gaussians, K = 16, vis mask, five-term loss, Adam) with a two-tensor
             # stand-in for the StyleUNet: a rasterizer + loss + optimiser number, not a config-4 number
             "s3_graph_step_standin_net_iters_per_sec": None if s3_vps is None else round(s3_vps, 2),

@@ -43,6 +43,8 @@ struct LossArgs {
     float* dL_dimg;                   // [V][3][H][W]
     const uint32_t* tile_count;       // region-of-interest form: [V][tgy * tgx] list lengths of the forward's 16x16 tiles, or null
     int tgx, tgy;
+    const uint32_t* mask_tiles;       // sparse-mask form: [V][tgy * tgx] non-zero mask pixels per 16x16 tile (ggs_mask_tiles), or null
+    const uint32_t* const* mask_tiles_tab;   //          ... or a device array of V device pointers to [tgy * tgx] tables
 };
 
 // Region of interest.  dL/dimage reaches a parameter only through pixels of tiles that HAVE a list (the render backward returns
@@ -54,15 +56,16 @@ struct LossArgs {
 // LH + LS_HB_ROI - 1 rows of the non-empty tile that made it active -- pass A stores the maps of a box iff a non-empty tile
 // lies within that distance of it, and skips the derivative arithmetic otherwise; its sums cover every pixel as before.
 // any_tile: does a non-empty tile of view v intersect the pixel rectangle [x0, x1] x [y0, y1]?  (wave-uniform result)
-__device__ __forceinline__ bool any_tile(const LossArgs& a, int v, int x0, int y0, int x1, int y1, int lane) {
+// (tc: the view's table -- list lengths of the forward, or the mask's tile occupancy of the sparse-mask form)
+__device__ __forceinline__ bool any_tile(const uint32_t* __restrict__ tc, const LossArgs& a, int x0, int y0, int x1, int y1, int lane) {
     const int tx0 = max(x0, 0) >> 4, tx1 = min(min(x1, a.W - 1) >> 4, a.tgx - 1);
     const int ty0 = max(y0, 0) >> 4, ty1 = min(min(y1, a.H - 1) >> 4, a.tgy - 1);
     const int nx = tx1 - tx0 + 1, n = nx * (ty1 - ty0 + 1);
-    const uint32_t* tc = a.tile_count + (size_t)v * a.tgx * a.tgy;
     bool hit = false;
     for (int i = lane; i < n; i += 64) hit |= tc[(size_t)(ty0 + i / nx) * a.tgx + tx0 + i % nx] != 0;
     return __builtin_amdgcn_ballot_w64(hit) != 0;
 }
+__device__ __forceinline__ const uint32_t* view_tiles(const LossArgs& a, int v) { return a.tile_count + (size_t)v * a.tgx * a.tgy; }
 
 template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* s_red) {
@@ -188,6 +191,7 @@ struct StatsCtx {
     float (*ss)[LS_IN];
     float (*sp)[LS_IN];
     float l1, ssum;
+    float s0;                 // sparse-mask form: the SSIM value of an all-zero window (ssum then collects S - s0)
     StatsRow nxt;
 #if GGS_LOSS_AHEAD == 2
     StatsRow nxt2;            // the row after `nxt`, in flight
@@ -196,7 +200,20 @@ struct StatsCtx {
     bool pend;
 };
 
-template <int R, bool MASK>
+// SSIM value of a window from its four filtered moments (+ the factors the derivative maps reuse)
+struct SsimTerms { float S, A1, A2, iB1, iB2, inv; };
+__device__ __forceinline__ SsimTerms ssim_terms(float m1, float m2, float ess, float e12) {
+    SsimTerms t;
+    const float mm = m1 * m1 + m2 * m2, cv = e12 - m1 * m2;          // ess - mm = sigma1^2 + sigma2^2
+    t.A1 = 2.f * m1 * m2 + SSIM_C1; t.A2 = 2.f * cv + SSIM_C2;
+    const float B1 = mm + SSIM_C1, B2 = (ess - mm) + SSIM_C2;
+    t.iB1 = __builtin_amdgcn_rcpf(B1); t.iB2 = __builtin_amdgcn_rcpf(B2);
+    t.inv = t.iB1 * t.iB2;
+    t.S = t.A1 * t.A2 * t.inv;
+    return t;
+}
+
+template <int R, bool MASK, int HB, bool SPARSE>
 __device__ __forceinline__ void stats_step(StatsCtx& c, RowRing<4>& ring, int i) {
     const int buf = i & 1;
     const int lane = c.lane;
@@ -232,7 +249,7 @@ __device__ __forceinline__ void stats_step(StatsCtx& c, RowRing<4>& ring, int i)
 #pragma unroll
         for (int k = 0; k < 11; ++k) { h[0] = fmaf(G11[k], xs[k], h[0]); h[1] = fmaf(G11[k], ys[k], h[1]); }
         // L1 over the strip's own pixels (the row is an own row when LH <= i < LH + LS_HB)
-        if (i >= LH && i < LH + LS_HB && c.oy + i - LH < c.H && x < c.W) c.l1 += fabsf(xs[LH] - ys[LH]);
+        if (i >= LH && i < LH + HB && c.oy + i - LH < c.H && x < c.W) c.l1 += fabsf(xs[LH] - ys[LH]);
     }
 #if GGS_LOSS_SPLIT_READS
     asm volatile("" ::: "memory");                   // keeps the second group's LDS reads behind the first group's use
@@ -251,18 +268,14 @@ __device__ __forceinline__ void stats_step(StatsCtx& c, RowRing<4>& ring, int i)
     c.pend = o >= 0 && c.oy + o < c.H && x < c.W;
     {
         constexpr int slot = (R + 1) % 11;
-        const float m1 = ring.v[slot][0], m2 = ring.v[slot][1], ess = ring.v[slot][2], e12 = ring.v[slot][3];
-        const float mm = m1 * m1 + m2 * m2, cv = e12 - m1 * m2;          // ess - mm = sigma1^2 + sigma2^2
-        const float A1 = 2.f * m1 * m2 + SSIM_C1, A2 = 2.f * cv + SSIM_C2;
-        const float B1 = mm + SSIM_C1, B2 = (ess - mm) + SSIM_C2;
-        const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
-        const float inv = iB1 * iB2;
-        const float S = A1 * A2 * inv;
-        if (c.pend) c.ssum += S;
+        const float m1 = ring.v[slot][0], m2 = ring.v[slot][1];
+        const SsimTerms t = ssim_terms(m1, m2, ring.v[slot][2], ring.v[slot][3]);
+        const float S = t.S;
+        if (c.pend) c.ssum += SPARSE ? S - c.s0 : S;
         if (c.dm) {                                  // wave-uniform: null where nobody will read the maps of this box
-            c.o0 = 2.f * m2 * (A2 - A1) * inv - 2.f * m1 * S * iB1 + 2.f * m1 * S * iB2;
-            c.o1 = -S * iB2;
-            c.o2 = 2.f * A1 * inv;
+            c.o0 = 2.f * m2 * (t.A2 - t.A1) * t.inv - 2.f * m1 * S * t.iB1 + 2.f * m1 * S * t.iB2;
+            c.o1 = -S * t.iB2;
+            c.o2 = 2.f * t.A1 * t.inv;
         }
     }
 }
@@ -274,12 +287,22 @@ __device__ __forceinline__ void unroll11(Ctx& c, Ring& ring, int i0) {
         unroll11<R + 1, Step>(c, ring, i0);
     }
 }
-template <bool MASK>
+template <bool MASK, int HB, bool SPARSE>
 struct StatsStep {
-    template <int R> static __device__ __forceinline__ void run(StatsCtx& c, RowRing<4>& r, int i) { stats_step<R, MASK>(c, r, i); }
+    template <int R> static __device__ __forceinline__ void run(StatsCtx& c, RowRing<4>& r, int i) { stats_step<R, MASK, HB, SPARSE>(c, r, i); }
 };
 
-template <bool MASK, int NCH>
+// Sparse-mask form (SPARSE; single-view launches use bands of LS_HB_SPARSE rows).  A real mask is the silhouette of the garment: ~90 %
+// of a 1080p frame is masked out, and there the masked x and y are zero, every window statistic is zero and the SSIM value
+// is ONE constant s0 = C1 C2 / (C1 C2) in the kernel's own arithmetic.  With the mask's tile occupancy at hand (ggs_mask_tiles:
+// computed once per mask, the masks of a capture are static) a wave whose input window holds no mask pixel, and whose maps no
+// box of pass B will read, does nothing at all.  The sum is kept as  sum over the computed pixels of (S - s0)  +  3 H W s0
+// (the constant is added once per view, by workgroup (0, 0)), so a skipped pixel needs no contribution of its own -- and the
+// chip is no longer filled by one round of 34-row bands: the few boxes that remain run as SHORT bands (22 dependent row
+// steps instead of 44), the shape that lost on a dense image for lack of wave slots (see LS_HB).
+// Measured (profiles/r05_sparse_mask_loss.md; 1080p, silhouette of 16 %): one view 45.3 -> 31.2 us (23-row bands 33.6, 34-row
+// bands 39.7), 16 views 32.7 -> 13.2 us per view; on a dense mask, where nothing is skipped, the short bands cost 1.45x.
+template <bool MASK, int NCH, int HB, bool SPARSE>
 __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float (*s_x)[4][2][LS_IN], float* s_red) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
     const int v = NCH == 3 ? blockIdx.z : blockIdx.z / 3, ch = NCH == 3 ? wave / LS_WAVES : blockIdx.z % 3;
@@ -290,13 +313,23 @@ __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float 
     c.gt = a.gt_tab ? a.gt_tab[v] + (size_t)ch * HW : a.gt + ((size_t)v * 3 + ch) * HW;
     c.mask = !MASK ? nullptr : a.mask_tab ? a.mask_tab[v] : a.mask + (size_t)v * HW;
     c.dm = a.dmap + ((size_t)v * 3 + ch) * 3 * HW; c.dm1 = c.dm + HW; c.dm2 = c.dm + 2 * HW;
-    c.H = a.H; c.W = a.W; c.oy = band * LS_HB; c.ox = blockIdx.x * LS_COLS; c.lane = lane; c.HW = HW;
+    c.H = a.H; c.W = a.W; c.oy = band * HB; c.ox = blockIdx.x * LS_COLS; c.lane = lane; c.HW = HW;
     c.sx = s_x[wave][0]; c.sy = s_x[wave][1]; c.ss = s_x[wave][2]; c.sp = s_x[wave][3];
-    c.l1 = 0.f; c.ssum = 0.f; c.pend = false; c.o0 = c.o1 = c.o2 = 0.f;
-    if (a.tile_count && c.oy < a.H &&
-        !any_tile(a, v, c.ox - LS_COLS, c.oy - (LH + LS_HB_ROI - 1), c.ox + 2 * LS_COLS - 1, c.oy + LS_HB - 1 + LH + LS_HB_ROI - 1, lane))
+    c.l1 = 0.f; c.ssum = 0.f; c.pend = false; c.o0 = c.o1 = c.o2 = 0.f; c.s0 = 0.f;
+    bool run = c.oy < a.H;
+    if (a.tile_count && run &&
+        !any_tile(view_tiles(a, v), a, c.ox - LS_COLS, c.oy - (LH + LS_HB_ROI - 1), c.ox + 2 * LS_COLS - 1,
+                  c.oy + HB - 1 + LH + LS_HB_ROI - 1, lane))
         c.dm = nullptr;
-    if (c.oy < a.H) {
+    if (SPARSE) {
+        float z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));          // a zero the compiler cannot fold: s0 through the kernel's own instructions
+        c.s0 = ssim_terms(z, z, z, z).S;
+        const uint32_t* mt = a.mask_tiles_tab ? a.mask_tiles_tab[v] : a.mask_tiles + (size_t)v * a.tgx * a.tgy;
+        // nothing to do iff nobody reads the maps of this box AND no mask pixel lies in its input window
+        if (run && !c.dm && !any_tile(mt, a, c.ox - LH, c.oy - LH, c.ox + LS_COLS - 1 + LH, c.oy + HB - 1 + LH, lane)) run = false;
+    }
+    if (run) {
         RowRing<4> ring;
 #pragma unroll
         for (int j = 0; j < 11; ++j)
@@ -306,34 +339,56 @@ __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float 
 #if GGS_LOSS_AHEAD == 2
         c.nxt2 = stats_load_row<MASK>(c.img, c.gt, c.mask, c.oy - LH + 1, c.H, c.W, c.ox, lane);
 #endif
-        for (int i0 = 0; i0 < LS_HB + 2 * LH; i0 += 11) unroll11<0, StatsStep<MASK>>(c, ring, i0);
+        static_assert((HB + 2 * LH) % 11 == 0, "the row loop is unrolled by 11");
+        for (int i0 = 0; i0 < HB + 2 * LH; i0 += 11) unroll11<0, StatsStep<MASK, HB, SPARSE>>(c, ring, i0);
         if (c.pend && c.dm) {                                            // the last output row
-            const uint32_t p = ((uint32_t)(c.oy + LS_HB - 1) * (uint32_t)c.W + (uint32_t)(c.ox + lane)) * 4u;
+            const uint32_t p = ((uint32_t)(c.oy + HB - 1) * (uint32_t)c.W + (uint32_t)(c.ox + lane)) * 4u;
             st_off(c.dm, p, c.o0); st_off(c.dm1, p, c.o1); st_off(c.dm2, p, c.o2);
         }
     }
-    const float l1 = block_sum<NCH * LS_WAVES>(c.l1, s_red), ssum = block_sum<NCH * LS_WAVES>(c.ssum, s_red);
+    float l1 = block_sum<NCH * LS_WAVES>(c.l1, s_red), ssum = block_sum<NCH * LS_WAVES>(c.ssum, s_red);
     if (threadIdx.x == 0) {
-        atomicAdd(&a.sums[2 * v], l1);
-        atomicAdd(&a.sums[2 * v + 1], ssum);
+        if (SPARSE) {       // the constant part, once per view; workgroups that skipped everything end without an atomic
+            if (blockIdx.x == 0 && blockIdx.y == 0 && (NCH == 3 || ch == 0)) ssum += 3.f * (float)a.H * (float)a.W * c.s0;
+            if (l1 != 0.f) atomicAdd(&a.sums[2 * v], l1);
+            if (ssum != 0.f) atomicAdd(&a.sums[2 * v + 1], ssum);
+        } else {
+            atomicAdd(&a.sums[2 * v], l1);
+            atomicAdd(&a.sums[2 * v + 1], ssum);
+        }
     }
 }
 
 }  // namespace
 
-// Pass A: grid (ceil(W/64), ceil(ceil(H/34)/4), V * 3 / NCH), block 256 NCH = 4 NCH independent waves.
+// Pass A: grid (ceil(W/64), ceil(ceil(H/HB)/4), V * 3 / NCH), block 256 NCH = 4 NCH independent waves.
 // (Masked and unmasked forms are separate kernels: as two branches of one kernel the register allocation of the shared
 // prologue pushed the masked body over its register budget.)
-#define GGS_LOSS_STATS_KERNEL(NAME, MASK, NCH)                                                                              \
+#ifndef LS_HB_SPARSE                      // 12, 23 or 34 (LS_HB_SPARSE + 10 must be a multiple of 11)
+#define LS_HB_SPARSE 12
+#endif
+#define GGS_LOSS_STATS_KERNEL(NAME, MASK, NCH, HB, SPARSE)                                                                  \
     __global__ __launch_bounds__(256 * NCH) __attribute__((amdgpu_waves_per_eu(GGS_LOSS_WAVES, GGS_LOSS_WAVES))) void NAME(LossArgs a) { \
         __shared__ float s_x[LS_WAVES * NCH][4][2][LS_IN];                                                                  \
         __shared__ float s_red[LS_WAVES * NCH];                                                                             \
-        loss_stats_stream_body<MASK, NCH>(a, s_x, s_red);                                                                   \
+        loss_stats_stream_body<MASK, NCH, HB, SPARSE>(a, s_x, s_red);                                                       \
     }
-GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats, false, 1)
-GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats_masked, true, 1)
-GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats_ch3, false, 3)
-GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats_masked_ch3, true, 3)
+GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats, false, 1, LS_HB, false)
+GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats_masked, true, 1, LS_HB, false)
+GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats_ch3, false, 3, LS_HB, false)
+GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats_masked_ch3, true, 3, LS_HB, false)
+GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats_sparse, true, 1, LS_HB, true)
+GGS_LOSS_STATS_KERNEL(ggs_k_loss_stats_sparse_ch3, true, 3, LS_HB_SPARSE, true)
+
+// Tile occupancy of a mask: tiles[v][ty * ceil(W/16) + tx] = number of non-zero pixels of mask v in that 16x16 tile.
+__global__ __launch_bounds__(256) void ggs_k_mask_tiles(int H, int W, int tgx, int tgy, const float* __restrict__ mask,
+                                                        uint32_t* __restrict__ tiles) {
+    const int t = blockIdx.x, v = blockIdx.y;
+    const int x = (t % tgx) * 16 + (threadIdx.x & 15), y = (t / tgx) * 16 + (threadIdx.x >> 4);
+    const bool nz = x < W && y < H && mask[(size_t)v * H * W + (size_t)y * W + x] != 0.f;
+    const int n = __syncthreads_count(nz);
+    if (threadIdx.x == 0) tiles[(size_t)v * tgx * tgy + t] = (uint32_t)n;
+}
 
 namespace {
 
@@ -427,7 +482,7 @@ __device__ __forceinline__ void loss_grad_stream_body(const LossArgs& a, float (
     c.sd = s_d[wave];
     c.pend = false; c.o0 = 0.f;
     if (c.oy >= a.H) return;
-    if (a.tile_count && !any_tile(a, v, c.ox, c.oy, c.ox + LS_COLS - 1, c.oy + HB - 1, lane)) return;
+    if (a.tile_count && !any_tile(view_tiles(a, v), a, c.ox, c.oy, c.ox + LS_COLS - 1, c.oy + HB - 1, lane)) return;
     RowRing<3> ring;
 #pragma unroll
     for (int j = 0; j < 11; ++j)
@@ -473,11 +528,13 @@ static int loss_args(LossArgs& a, int n_views, int H, int W, const float* img, c
     a.inv_n = 1.f / (3.f * (float)H * (float)W);
     a.w = nullptr; a.sums = nullptr; a.dL_dimg = nullptr; a.dmap = (float*)scratch;
     a.tile_count = tile_count; a.tgx = (W + 15) / 16; a.tgy = (H + 15) / 16;
+    a.mask_tiles = nullptr; a.mask_tiles_tab = nullptr;
     return GGS_OK;
 }
 
 static int photometric_forward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
                                const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count,
+                               const uint32_t* mask_tiles, const uint32_t* const* mask_tiles_tab,
                                float* sums, void* scratch, void* stream_) {
     LossArgs a;
     int rc = loss_args(a, n_views, H, W, img, gt, mask, gt_tab, mask_tab, tile_count, scratch, "ggs_photometric_forward");
@@ -487,12 +544,20 @@ static int photometric_forward(int n_views, int H, int W, const float* img, cons
     a.sums = sums;
     if (ggs_zero_async(sums, (size_t)n_views * 2 * sizeof(float), s) != hipSuccess)
         return ggs_fail_(GGS_ERR_HIP, "ggs_photometric_forward: clearing the sums failed");
-    const int bands = (H + LS_HB - 1) / LS_HB;
     const bool ch3 = n_views <= LS_CH3_MAX_VIEWS;
+    const bool masked = a.mask || a.mask_tab;
+    const bool sparse = mask_tiles || mask_tiles_tab;
+    if (sparse && !(masked && tile_count))
+        return ggs_fail_(GGS_ERR_ARG, "ggs_photometric_forward_sparse: the mask's tile table needs the mask and the forward's tile_count");
+    a.mask_tiles = mask_tiles; a.mask_tiles_tab = mask_tiles_tab;
+    const int hb = sparse && ch3 ? LS_HB_SPARSE : LS_HB;
+    const int bands = (H + hb - 1) / hb;
     const dim3 grid((unsigned)((W + LS_COLS - 1) / LS_COLS), (unsigned)((bands + LS_WAVES - 1) / LS_WAVES),
                     (unsigned)(ch3 ? n_views : n_views * 3));
-    const bool masked = a.mask || a.mask_tab;
-    if (ch3 && masked) hipLaunchKernelGGL(ggs_k_loss_stats_masked_ch3, grid, dim3(768), 0, s, a);
+    if (grid.y > 65535u) return ggs_fail_(GGS_ERR_SIZE, "ggs_photometric_forward: image too tall");
+    if (sparse && ch3) hipLaunchKernelGGL(ggs_k_loss_stats_sparse_ch3, grid, dim3(768), 0, s, a);
+    else if (sparse) hipLaunchKernelGGL(ggs_k_loss_stats_sparse, grid, dim3(256), 0, s, a);
+    else if (ch3 && masked) hipLaunchKernelGGL(ggs_k_loss_stats_masked_ch3, grid, dim3(768), 0, s, a);
     else if (ch3) hipLaunchKernelGGL(ggs_k_loss_stats_ch3, grid, dim3(768), 0, s, a);
     else if (masked) hipLaunchKernelGGL(ggs_k_loss_stats_masked, grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL(ggs_k_loss_stats, grid, dim3(256), 0, s, a);
@@ -521,7 +586,7 @@ static int photometric_backward(int n_views, int H, int W, const float* img, con
 
 int ggs_photometric_forward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
                             float* sums, void* scratch, void* stream) {
-    return photometric_forward(n_views, H, W, img, gt, mask, nullptr, nullptr, nullptr, sums, scratch, stream);
+    return photometric_forward(n_views, H, W, img, gt, mask, nullptr, nullptr, nullptr, nullptr, nullptr, sums, scratch, stream);
 }
 int ggs_photometric_backward(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
                              const void* scratch, const float* weights, float* dL_dimg, void* stream) {
@@ -532,7 +597,7 @@ int ggs_photometric_backward(int n_views, int H, int W, const float* img, const 
 // 33 MB into static buffers.
 int ggs_photometric_forward_tab(int n_views, int H, int W, const float* img, const float* const* gt_tab,
                                 const float* const* mask_tab, float* sums, void* scratch, void* stream) {
-    return photometric_forward(n_views, H, W, img, nullptr, nullptr, gt_tab, mask_tab, nullptr, sums, scratch, stream);
+    return photometric_forward(n_views, H, W, img, nullptr, nullptr, gt_tab, mask_tab, nullptr, nullptr, nullptr, sums, scratch, stream);
 }
 int ggs_photometric_backward_tab(int n_views, int H, int W, const float* img, const float* const* gt_tab,
                                  const float* const* mask_tab, const void* scratch, const float* weights, float* dL_dimg,
@@ -546,12 +611,41 @@ int ggs_photometric_backward_tab(int n_views, int H, int W, const float* img, co
 int ggs_photometric_forward_roi(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
                                 const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count,
                                 float* sums, void* scratch, void* stream) {
-    return photometric_forward(n_views, H, W, img, gt, mask, gt_tab, mask_tab, tile_count, sums, scratch, stream);
+    return photometric_forward(n_views, H, W, img, gt, mask, gt_tab, mask_tab, tile_count, nullptr, nullptr, sums, scratch, stream);
 }
 int ggs_photometric_backward_roi(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
                                  const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count,
                                  const void* scratch, const float* weights, float* dL_dimg, void* stream) {
     return photometric_backward(n_views, H, W, img, gt, mask, gt_tab, mask_tab, tile_count, scratch, weights, dL_dimg, stream);
+}
+// Sparse-mask form of pass A (see loss_stats_stream_body): as ggs_photometric_forward_roi, plus the tile occupancy of the masks
+// (ggs_mask_tiles; by plain pointer [n_views][tiles] or by a device table of per-view pointers) -- boxes without a mask pixel
+// in their window and without a reader of their maps are skipped.  Same sums (to fp32 rounding of the summation order), same
+// maps where pass B reads them: ggs_photometric_backward_roi follows unchanged.  Meant for silhouette masks; on a dense mask
+// nothing is skipped and the single-view launch pays for its short bands (~1.6x the plain form).
+int ggs_photometric_forward_sparse(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
+                                   const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count,
+                                   const uint32_t* mask_tiles, const uint32_t* const* mask_tiles_tab,
+                                   float* sums, void* scratch, void* stream) {
+    if (!mask_tiles && !mask_tiles_tab) {
+        ggs_clear_error_();
+        return ggs_fail_(GGS_ERR_ARG, "ggs_photometric_forward_sparse: NULL mask tile table");
+    }
+    return photometric_forward(n_views, H, W, img, gt, mask, gt_tab, mask_tab, tile_count, mask_tiles, mask_tiles_tab, sums,
+                               scratch, stream);
+}
+// tiles[v][ty * ceil(W/16) + tx] = number of non-zero pixels of mask v ([n_views][H][W] floats) in the 16x16 tile (tx, ty)
+int ggs_mask_tiles(int n_views, int H, int W, const float* mask, uint32_t* tiles, void* stream) {
+    ggs_clear_error_();
+    if (n_views <= 0 || H <= 0 || W <= 0) return ggs_fail_(GGS_ERR_ARG, "ggs_mask_tiles: bad sizes");
+    if (!mask || !tiles) return ggs_fail_(GGS_ERR_ARG, "ggs_mask_tiles: NULL pointer argument");
+    if (n_views > 65535) return ggs_fail_(GGS_ERR_SIZE, "ggs_mask_tiles: n_views too large");
+    const int tgx = (W + 15) / 16, tgy = (H + 15) / 16;
+    hipLaunchKernelGGL(ggs_k_mask_tiles, dim3((unsigned)(tgx * tgy), (unsigned)n_views), dim3(256), 0, (hipStream_t)stream, H, W,
+                       tgx, tgy, mask, tiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ggs_fail_(GGS_ERR_HIP, "ggs_mask_tiles launch failed: %s", hipGetErrorString(e));
+    return GGS_OK;
 }
 
 }  // extern "C"

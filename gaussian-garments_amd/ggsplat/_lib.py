@@ -65,6 +65,8 @@ _SIGS = {
     "ggs_photometric_backward_tab": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 7),
     "ggs_photometric_forward_roi": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 9),
     "ggs_photometric_backward_roi": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 10),
+    "ggs_photometric_forward_sparse": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 11),
+    "ggs_mask_tiles": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 3),
     "ggs_dist2_3nn": (C.c_int, [C.c_int, _PTR, _PTR, _PTR]),
     "ggs_dist2_3nn_scratch_bytes": (C.c_size_t, [C.c_int]),
     "ggs_dist2_3nn_grid": (C.c_int, [C.c_int, _PTR, _PTR, _PTR, _PTR]),

@@ -173,13 +173,16 @@ def appearance_step(gaussians, net: Callable, viewpoint_cam, gt_image, mask, bg,
     return loss_dict
 
 
+_BLK_BYTES = 184            # the per-iteration parameter block of the captured steps (see GraphedRegistrationStep.__init__)
+
+
 class GraphedRegistrationStep:
     """The s2 inner iteration (registration_step above: bind -> render -> L1/SSIM [+ hinges] -> backward ->
     densification stats -> Adam) captured ONCE into a hipGraph and replayed per iteration.
 
     The reference's loop is launch- and sync-bound on a fast GPU: ~60 small kernels and several host round trips
-    per iteration for ~1 ms of GPU work.  A replay is one graph launch behind ONE 176-byte H2D copy (camera matrices,
-    tangents and the device addresses of this iteration's ground truth / mask, which the loss kernels read through a
+    per iteration for ~1 ms of GPU work.  A replay is one graph launch behind ONE 184-byte H2D copy (camera matrices,
+    tangents and the device addresses of this iteration's ground truth / mask / mask tile table, which the loss kernels read through a
     pointer table -- images already on the GPU are not copied) and in front of ONE 48-byte read-back (loss statistics +
     the rasterizer's overflow word); the learning rates live on the device (GraphAdam.push_lr).  The rasterizer
     runs with the binning capacity learnt during the eager warm-up; if a replayed step overflows it, the guarded
@@ -197,24 +200,30 @@ class GraphedRegistrationStep:
 
     def __init__(self, gaussians, W: int, H: int, bg, opt=DEFAULT_OPT, pipe=DEFAULT_PIPE,
                  first_frame_template: bool = True, track_densification: bool = True, use_mask: bool = True,
-                 capacity_slack: float = 1.0, lean: bool = True):
+                 capacity_slack: float = 1.0, lean: bool = True, sparse_mask: Optional[bool] = None):
         if not isinstance(gaussians.optimizer, GraphAdam):
             raise TypeError("GraphedRegistrationStep needs gaussians.optimizer to be a ggsplat.adam.GraphAdam")
         dev = gaussians._xyz.device
         self.g, self.opt, self.pipe, self.bg = gaussians, opt, pipe, bg
         self.fft, self.track = first_frame_template, track_densification
-        # Everything that changes from one iteration to the next sits in ONE 176-byte device block, refreshed by one H2D copy
+        # Everything that changes from one iteration to the next sits in ONE 184-byte device block, refreshed by one H2D copy
         # from a pinned staging block: view [16] | full projection [16] | camera centre [3] | tan(fov/2) [2] | pad [3] floats,
-        # then two device pointers (ground truth, mask) that the loss kernels read through (ggs_photometric_*_tab).
-        self._blk = torch.zeros(176, dtype=torch.uint8, device=dev)
-        self._blk_host = torch.zeros(176, dtype=torch.uint8).pin_memory()
+        # then three device pointers (ground truth, mask, the mask's tile occupancy) that the loss kernels read through
+        # (ggs_photometric_*_tab / _sparse).
+        self._blk = torch.zeros(_BLK_BYTES, dtype=torch.uint8, device=dev)
+        self._blk_host = torch.zeros(_BLK_BYTES, dtype=torch.uint8).pin_memory()
         f = self._blk[:160].view(torch.float32)
         self.cam = SimpleNamespace(
             image_height=H, image_width=W, world_view_transform=f[0:16].view(4, 4), full_proj_transform=f[16:32].view(4, 4),
             camera_center=f[32:35], tanfov=f[35:37].view(1, 2))
-        self._ptrs = self._blk[160:176].view(torch.int64)
+        self._ptrs = self._blk[160:_BLK_BYTES].view(torch.int64)
         self._host_f = self._blk_host[:160].view(torch.float32)
-        self._host_p = self._blk_host[160:176].view(torch.int64)
+        self._host_p = self._blk_host[160:_BLK_BYTES].view(torch.int64)
+        # Sparse-mask form of the loss's first pass (ggs_photometric_forward_sparse; lean form only): True / False, or None =
+        # decided by the first mask this object sees (a silhouette that leaves most 16x16 tiles empty -> True).  The choice is
+        # part of the captured graph; a later mask of the other kind still gives the right numbers, only not the faster kernel.
+        self._sparse = sparse_mask if (lean and use_mask and opt.only_foreground_loss) else False
+        self._mask_tiles: Dict[int, tuple] = {}
         self._cam_cache: Dict[int, tuple] = {}
         self._keep = None                                   # the tensors the pointer table names, alive until the replay is done
         self.gt = torch.zeros(3, H, W, device=dev)          # landing buffers for images that arrive on the host
@@ -269,14 +278,32 @@ class GraphedRegistrationStep:
         landing.copy_(t.reshape(shape), non_blocking=True)
         return landing
 
+    def _tiles_of(self, m):
+        """Tile occupancy of mask tensor `m` (ggs_mask_tiles), computed once per (tensor, version); the first one also settles
+        sparse_mask=None: sparse iff fewer than half of the tiles hold a mask pixel (one read-back, once)."""
+        from .loss import mask_tile_occupancy
+        ent = self._mask_tiles.get(id(m))
+        if ent is None or ent[0] is not m or ent[1] != m._version:
+            if len(self._mask_tiles) > 4096:
+                self._mask_tiles.clear()
+            ent = self._mask_tiles[id(m)] = (m, m._version, mask_tile_occupancy(m))
+        if self._sparse is None:
+            t = ent[2]
+            self._sparse = bool(int((t != 0).sum()) * 2 < t.numel())
+            if not self._sparse:
+                return None
+        return ent[2]
+
     def _load(self, cam, gt_image, mask):
         self._host_f[:40] = self._packed_camera(cam)
         gt = self._resident(gt_image, self.gt, self.gt.shape)
         m = None
         if self.mask is not None:
             m = self.mask if mask is None else self._resident(mask, self.mask, self.mask.shape)
-        self._keep = (gt, m)
+        mt = self._tiles_of(m) if (m is not None and self._sparse is not False) else None
+        self._keep = (gt, m, mt)
         self._host_p[0], self._host_p[1] = gt.data_ptr(), (m.data_ptr() if m is not None else 0)
+        self._host_p[2] = mt.data_ptr() if mt is not None else 0
         if not self._blk_map:
             self._blk.copy_(self._blk_host, non_blocking=True)
         if not self.lean:           # the autograd form reads the images from the static buffers
@@ -323,7 +350,7 @@ class GraphedRegistrationStep:
                 pro.clear_ptr[i], pro.clear_bytes[i] = t.data_ptr(), n
                 pro.consumer_mask |= int(consumed) << i
             if self._blk_map:
-                pro.copy_src, pro.copy_dst, pro.copy_bytes = self._blk_map, self._blk.data_ptr(), 176
+                pro.copy_src, pro.copy_dst, pro.copy_bytes = self._blk_map, self._blk.data_ptr(), _BLK_BYTES
             pro.P, pro.F = P, Fn
             pro.verts, pro.faces, pro.binding = ptr(verts), ptr(faces), ptr(binding)
             pro.local_xyz, pro.log_scaling, pro.raw_rot, pro.bary = ptr(g._xyz), ptr(g._scaling), ptr(g._rotation), ptr(bary)
@@ -341,8 +368,13 @@ class GraphedRegistrationStep:
             scratch = torch.empty(L.ggs_photometric_scratch_bytes(1, H, W), device=dev, dtype=torch.uint8)
             # region-of-interest form: dL/dimage only where the backward below reads it (tiles with a list: ~1 in 10 here)
             tc = R.last_tile_count()
-            check(L.ggs_photometric_forward_roi(1, H, W, ptr(color), None, None, ptr(gt_tab), ptr(m_tab), ptr(tc),
-                                                ptr(self._sums), ptr(scratch), stream), "ggs_photometric_forward_roi")
+            if use_m and self._sparse:       # silhouette mask: the boxes without a mask pixel are skipped
+                check(L.ggs_photometric_forward_sparse(1, H, W, ptr(color), None, None, ptr(gt_tab), ptr(m_tab), ptr(tc), None,
+                                                       ptr(self._ptrs[2:3]), ptr(self._sums), ptr(scratch), stream),
+                      "ggs_photometric_forward_sparse")
+            else:
+                check(L.ggs_photometric_forward_roi(1, H, W, ptr(color), None, None, ptr(gt_tab), ptr(m_tab), ptr(tc),
+                                                    ptr(self._sums), ptr(scratch), stream), "ggs_photometric_forward_roi")
             dimg = torch.empty_like(color)
             check(L.ggs_photometric_backward_roi(1, H, W, ptr(color), None, None, ptr(gt_tab), ptr(m_tab), ptr(tc), ptr(scratch),
                                                  ptr(self._w), ptr(dimg), stream), "ggs_photometric_backward_roi")
@@ -504,7 +536,7 @@ class PipelinedRegistrationStep:
     iteration i read while iteration i + 1 runs.
 
     A replayed iteration is ~0.35 ms of kernels; a caller that waits for each result before it queues the next iteration leaves
-    the GPU idle for the host's share of the period -- writing the 176-byte parameter block, hipGraphLaunch, waking up from the
+    the GPU idle for the host's share of the period -- writing the 184-byte parameter block, hipGraphLaunch, waking up from the
     wait, reading the 48-byte result (~20-35 us per iteration).  Here iteration i + 1 is queued BEFORE the host
     waits for iteration i: the stream runs the two graphs back to back (parameters, optimiser state and statistics are shared:
     same addresses in both captures, so iteration i + 1 sees the update of iteration i), and every call returns the losses of the
@@ -521,6 +553,7 @@ class PipelinedRegistrationStep:
     def __init__(self, gaussians, W: int, H: int, bg, **kw):
         kw["lean"] = True
         self.steps = [GraphedRegistrationStep(gaussians, W, H, bg, **kw) for _ in range(2)]
+        self.steps[1]._mask_tiles = self.steps[0]._mask_tiles          # one tile table per mask, whichever copy meets it first
         self._pending: Optional[GraphedRegistrationStep] = None
         self._n = 0
 

@@ -72,7 +72,7 @@ def _consts(dev, lam, n):
 
 class _FusedPhotometric(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, image, gt, mask, lambda_dssim, tile_count=None):
+    def forward(ctx, image, gt, mask, lambda_dssim, tile_count=None, mask_tiles=None):
         import ctypes as C
         from ._lib import check, lib, ptr, stream_ptr
         if image.device.type != "cuda":
@@ -95,9 +95,24 @@ class _FusedPhotometric(torch.autograd.Function):
             tc = tile_count.contiguous()
             if tc.dtype not in (torch.int32, torch.uint32) or tc.numel() != V * ((H + 15) // 16) * ((W + 15) // 16):
                 raise ValueError("fused_photometric_loss: tile_count must be int32 [V, ceil(H/16) * ceil(W/16)]")
-        check(L.ggs_photometric_forward_roi(V, H, W, ptr(img), ptr(g), ptr(m), None, None, ptr(tc), ptr(sums), ptr(scratch),
-                                            stream_ptr(dev)),
-              "ggs_photometric_forward")
+        if mask_tiles is not None:
+            if m is None or tc is None:
+                raise ValueError("fused_photometric_loss: mask_tiles needs the mask and tile_count (the sparse-mask form skips "
+                                 "only the boxes whose derivative maps the region-of-interest backward does not read)")
+            mt = mask_tiles.contiguous()
+            if mt.dtype not in (torch.int32, torch.uint32) or mt.device != dev:
+                raise ValueError("fused_photometric_loss: mask_tiles must be the int32 device tensor mask_tile_occupancy() returns")
+            if mt.numel() == tc.numel() // V and V > 1:          # one mask for all views, like `mask`
+                mt = mt.reshape(1, -1).expand(V, -1).contiguous()
+            if mt.numel() != tc.numel():
+                raise ValueError("fused_photometric_loss: mask_tiles must hold ceil(H/16) * ceil(W/16) counts per view")
+            check(L.ggs_photometric_forward_sparse(V, H, W, ptr(img), ptr(g), ptr(m), None, None, ptr(tc), ptr(mt), None,
+                                                   ptr(sums), ptr(scratch), stream_ptr(dev)),
+                  "ggs_photometric_forward_sparse")
+        else:
+            check(L.ggs_photometric_forward_roi(V, H, W, ptr(img), ptr(g), ptr(m), None, None, ptr(tc), ptr(sums), ptr(scratch),
+                                                stream_ptr(dev)),
+                  "ggs_photometric_forward")
         lam = float(lambda_dssim)
         scale, bias, _ = _consts(dev, lam, 3.0 * H * W)
         # The backward re-reads the image.  It is NOT copied (24 MB per 1080p view): like the rasterizer's autograd node this
@@ -130,18 +145,37 @@ class _FusedPhotometric(torch.autograd.Function):
         check(lib().ggs_photometric_backward_roi(V, H, W, ptr(img), ptr(g), ptr(m), None, None, ptr(tc), ptr(scratch), ptr(w),
                                                  ptr(dimg), stream_ptr(dev)),
               "ggs_photometric_backward")
-        return dimg.reshape(in_shape), None, None, None, None
+        return dimg.reshape(in_shape), None, None, None, None, None
 
 
-def fused_photometric_loss(image, gt, mask=None, lambda_dssim: float = 0.2, tile_count=None):
+def mask_tile_occupancy(mask):
+    """int32 [V, ceil(H/16) * ceil(W/16)]: the number of non-zero pixels of each mask ([V,1,H,W], [1,H,W] or [H,W], on the GPU) per
+    16x16 tile -- the table the sparse-mask form of the fused loss takes (`mask_tiles=`).  Compute it ONCE per mask (the masks
+    of the loops are per-camera constants, s2_registration.py:246-258)."""
+    from ._lib import check, lib, ptr, stream_ptr
+    if mask.device.type != "cuda":
+        raise RuntimeError("ggsplat.mask_tile_occupancy runs on the GPU only (no CPU path in the product)")
+    H, W = mask.shape[-2:]
+    m = mask.detach().reshape(-1, H, W)
+    m = m if m.dtype is torch.float32 else m.float()
+    m = m if m.is_contiguous() else m.contiguous()
+    V = m.shape[0]
+    out = torch.empty(V, ((H + 15) // 16) * ((W + 15) // 16), device=m.device, dtype=torch.int32)
+    check(lib().ggs_mask_tiles(V, H, W, ptr(m), ptr(out), stream_ptr(m.device)), "ggs_mask_tiles")
+    return out
+
+
+def fused_photometric_loss(image, gt, mask=None, lambda_dssim: float = 0.2, tile_count=None, mask_tiles=None):
     """(l1_loss(image, gt, mask) * (1 - lambda), 1 - ssim(image, gt, mask) * lambda), per view when the inputs
     are batched [V,3,H,W], through the fused HIP kernels.  Unlike the reference's ssim() it does not mask
     `image` / `gt` in place (the masking happens inside the kernels).  The image is NOT copied for the backward: an in-place
     edit of it between this call and loss.backward() raises autograd's "modified by an inplace operation" error.
     tile_count (rasterizer.last_tile_count() of the forward that rendered `image`): region-of-interest form -- the loss
     VALUES are the same, the gradient w.r.t. the image is computed only where the rasterizer's backward reads it (pixels of
-    tiles that have a list) and is zero elsewhere: right for every parameter behind the rasterizer, not a full dL/dimage."""
-    l_img, l_ssim = _FusedPhotometric.apply(image, gt, mask, lambda_dssim, tile_count)
+    tiles that have a list) and is zero elsewhere: right for every parameter behind the rasterizer, not a full dL/dimage.
+    mask_tiles (mask_tile_occupancy(mask), with tile_count): sparse-mask form -- the forward pass skips the boxes that hold no
+    mask pixel; same values up to fp32 summation order, for silhouette masks (on a dense mask it is slower than without)."""
+    l_img, l_ssim = _FusedPhotometric.apply(image, gt, mask, lambda_dssim, tile_count, mask_tiles)
     if image.dim() == 3:
         return l_img[0], l_ssim[0]
     return l_img, l_ssim

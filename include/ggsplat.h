@@ -243,6 +243,21 @@ int ggs_photometric_forward_roi(int n_views, int H, int W, const float* img, con
 int ggs_photometric_backward_roi(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
                                  const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count,
                                  const void* scratch, const float* weights, float* dL_dimg, void* stream);
+/* Sparse-mask form of the forward pass.  The masks of the loops are garment silhouettes (`gt_mask` of
+ * s2_registration.py:246-258: the garment's label in the segmentation): most of a frame is masked out, and there x = y = 0,
+ * every window statistic is zero and the SSIM map is one constant.  `mask_tiles` = the tile occupancy of the masks
+ * (ggs_mask_tiles below: uint32 [n_views][ceil(H/16) * ceil(W/16)]; or `mask_tiles_tab`, a DEVICE array of n_views device
+ * pointers to one such table each, like mask_tab -- the masks of a capture are static, one table per mask, computed once).
+ * A 64-column box without a mask pixel in its input window, whose maps the backward pass will not read (tile_count is
+ * REQUIRED), is skipped; the constant part of the SSIM sum is added once per view.  `sums` are those of the plain form up to the
+ * fp32 rounding of a different summation order; ggs_photometric_backward_roi follows unchanged.  On a dense mask nothing is
+ * skipped and a one- or two-view launch pays ~1.6x for its short bands: use the _roi form there.  No reference counterpart. */
+int ggs_photometric_forward_sparse(int n_views, int H, int W, const float* img, const float* gt, const float* mask,
+                                   const float* const* gt_tab, const float* const* mask_tab, const uint32_t* tile_count,
+                                   const uint32_t* mask_tiles, const uint32_t* const* mask_tiles_tab,
+                                   float* sums, void* scratch, void* stream);
+/* tiles[v][ty * ceil(W/16) + tx] <- number of non-zero pixels of mask v (mask [n_views][H][W] floats) in the 16x16 tile (tx, ty). */
+int ggs_mask_tiles(int n_views, int H, int W, const float* mask, uint32_t* tiles, void* stream);
 
 /*
  * Mean squared distance of every point to its 3 nearest neighbours (self excluded) -- replaces

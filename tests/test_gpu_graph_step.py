@@ -465,3 +465,59 @@ def test_pipelined_registration_step_matches_the_sequential_replay(slack):
             assert float(ok.float().mean()) >= 0.995 and float((x - y).abs().mean()) <= 1e-5
         else:
             assert float((x - y).abs().mean()) <= 5e-3 and bool(torch.isfinite(x).all())
+
+
+def _silhouettes(cams, models_v_f_params, bg):
+    """garment silhouettes of the cameras: the initial model's own alpha > 0.05, as a segmentation mask would be"""
+    from ggsplat.inner_step import DEFAULT_PIPE
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    from ggsplat.render import render
+    v, f, params = models_v_f_params
+    m = MeshGaussianModel.from_tensors(v, f, params, sh_degree=0, device="cuda")
+    out = []
+    with torch.no_grad():
+        m.update_face_coor()
+        for c in cams:
+            out.append((render(c, m, DEFAULT_PIPE, bg)["alpha"] > 0.05).float().reshape(1, c.image_height, c.image_width).contiguous())
+    return out
+
+
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_lean_step_with_the_sparse_mask_loss_gives_the_same_trajectory(pipelined):
+    """sparse_mask=True (ggs_photometric_forward_sparse: the first loss pass skips the boxes without a mask pixel) against
+    sparse_mask=False on silhouette masks: same losses, same parameters; sparse_mask=None picks the sparse form for a
+    silhouette and the plain one for a dense mask."""
+    from ggsplat import rasterizer as R
+    from ggsplat.inner_step import DEFAULT_OPT, GraphedRegistrationStep, PipelinedRegistrationStep
+    opt = SimpleNamespace(**{**vars(DEFAULT_OPT), "threshold_xyz": 0.3, "threshold_scale": 0.02})
+    v, f, params, cams, gts, dense_masks = _scene(seed=5)
+    bg = torch.zeros(3, device="cuda")
+    masks = _silhouettes(cams, (v, f, params), bg)
+    frac = float(torch.stack(masks).mean())
+    assert 0.01 < frac < 0.45, frac
+    a, b, c = (_model(v, f, params, opt, True) for _ in range(3))
+    R._cap_hint.clear()
+    cls = PipelinedRegistrationStep if pipelined else GraphedRegistrationStep
+    plain, sparse, auto = cls(a, W, H, bg, opt=opt, sparse_mask=False), cls(b, W, H, bg, opt=opt, sparse_mask=True), cls(c, W, H, bg, opt=opt)
+    order = [0, 3, 1, 5, 2, 4, 0, 2]
+    outs = {0: [], 1: [], 2: []}
+    for ci in order:
+        for k, st in enumerate((plain, sparse, auto)):
+            outs[k].append(st(cams[ci], gts[ci], masks[ci]))
+    if pipelined:
+        for k, st in enumerate((plain, sparse, auto)):
+            outs[k] = outs[k][1:] + [st.flush()]
+    for o1, o2, o3 in zip(outs[0], outs[1], outs[2]):
+        for k in ("img", "ssim", "xyz", "scale", "loss", "n_visible"):
+            assert abs(o1[k] - o2[k]) <= 2e-5 * max(1.0, abs(o1[k])), (k, o1[k], o2[k])
+            assert abs(o1[k] - o3[k]) <= 2e-5 * max(1.0, abs(o1[k])), (k, o1[k], o3[k])
+    firsts = [st.steps[0] if pipelined else st for st in (plain, sparse, auto)]
+    assert [s._sparse for s in firsts] == [False, True, True]
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        if pa.numel():
+            ok = (pa.detach() - pb.detach()).abs() <= 2e-6 + 1e-4 * pa.detach().abs()
+            assert float(ok.float().mean()) >= 0.995 and float((pa.detach() - pb.detach()).abs().mean()) <= 1e-5
+    # a dense mask settles sparse_mask=None the other way
+    d = GraphedRegistrationStep(_model(v, f, params, opt, True), W, H, bg, opt=opt)
+    d(cams[0], gts[0], dense_masks[0])
+    assert d._sparse is False

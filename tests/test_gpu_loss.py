@@ -146,6 +146,133 @@ def test_region_of_interest_form(V, H, W, use_mask, density):
         assert box.all()
 
 
+def _blob_mask(V, H, W, g, kind):
+    """silhouette-like masks: a disc per view ("disc"), nothing ("empty"), everything ("full"), salt-and-pepper ("noise")"""
+    if kind == "empty":
+        return torch.zeros(V, 1, H, W)
+    if kind == "full":
+        return torch.ones(V, 1, H, W)
+    if kind == "noise":
+        return (torch.rand(V, 1, H, W, generator=g) > 0.3).float()
+    yy, xx = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
+    m = torch.zeros(V, 1, H, W)
+    for v in range(V):
+        cx, cy = W * (0.3 + 0.4 * float(torch.rand(1, generator=g))), H * (0.3 + 0.4 * float(torch.rand(1, generator=g)))
+        r = 0.18 * min(H, W)
+        m[v, 0] = (((xx - cx) ** 2 + (yy - cy) ** 2) < r * r).float()
+    return m
+
+
+@pytest.mark.parametrize("V,H,W", [(1, 200, 330), (2, 137, 130), (3, 70, 33), (1, 16, 16), (4, 97, 260)])
+def test_mask_tile_occupancy(V, H, W):
+    """ggs_mask_tiles: non-zero mask pixels per 16x16 tile, ragged edges included."""
+    from ggsplat.loss import mask_tile_occupancy
+    g = torch.Generator().manual_seed(V + H + W)
+    m = (torch.rand(V, 1, H, W, generator=g) > 0.6).float() * torch.rand(V, 1, H, W, generator=g)
+    m[:, :, : H // 2, : W // 3] = 0
+    got = mask_tile_occupancy(m.cuda())
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    pad = torch.zeros(V, gy * 16, gx * 16)
+    pad[:, :H, :W] = (m[:, 0] != 0).float()
+    want = pad.reshape(V, gy, 16, gx, 16).sum(dim=(2, 4)).reshape(V, gy * gx).int()
+    assert got.dtype is torch.int32 and torch.equal(got.cpu(), want)
+
+
+@pytest.mark.parametrize("V,H,W,kind,density", [(1, 360, 640, "disc", 0.05), (1, 200, 330, "disc", 0.15), (2, 137, 130, "disc", 0.1),
+                                                (3, 170, 233, "disc", 0.1), (1, 96, 128, "empty", 0.1), (1, 96, 128, "full", 0.2),
+                                                (1, 150, 200, "noise", 0.1), (4, 70, 33, "disc", 0.5), (1, 1080, 1920, "disc", 0.08)])
+def test_sparse_mask_form(V, H, W, kind, density):
+    """ggs_photometric_forward_sparse: the sums of the region-of-interest form to summation order, and -- behind the unchanged
+    backward pass -- its dL/dimage bit for bit on every box that pass writes (tiles with a list both inside and OUTSIDE the
+    mask: the maps of a masked-out box are still produced when the backward will read them)."""
+    import ctypes as C
+    from ggsplat._lib import check, lib, ptr
+    from ggsplat.loss import mask_tile_occupancy
+    L = lib()
+    dev = "cuda"
+    g = torch.Generator().manual_seed(V * 1000 + H + W)
+    img, gt = torch.rand(V, 3, H, W, generator=g).to(dev), torch.rand(V, 3, H, W, generator=g).to(dev)
+    mask = _blob_mask(V, H, W, g, kind).to(dev)
+    gx, gy = (W + 15) // 16, (H + 15) // 16
+    # lists where the mask is (the garment) plus a few anywhere (Gaussians that left the silhouette)
+    in_mask = mask_tile_occupancy(mask).cpu() != 0
+    tc = ((in_mask & (torch.rand(V, gy * gx, generator=g) < 0.8)) | (torch.rand(V, gy * gx, generator=g) < density * 0.2)).int() * 5
+    tc = tc.to(dev)
+    mt = mask_tile_occupancy(mask)
+    w = torch.tensor([[0.8, -0.2]] * V, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(sparse, table=False):
+        sums = torch.empty(V, 2, device=dev)
+        scratch = torch.full((L.ggs_photometric_scratch_bytes(V, H, W),), 0xFF, device=dev, dtype=torch.uint8)   # NaN maps
+        if sparse and table:
+            tabs = torch.tensor([mt[v].data_ptr() for v in range(V)], dtype=torch.int64, device=dev)
+            check(L.ggs_photometric_forward_sparse(V, H, W, ptr(img), ptr(gt), ptr(mask), None, None, ptr(tc), None, ptr(tabs),
+                                                   ptr(sums), ptr(scratch), stream), "fwd sparse (table)")
+        elif sparse:
+            check(L.ggs_photometric_forward_sparse(V, H, W, ptr(img), ptr(gt), ptr(mask), None, None, ptr(tc), ptr(mt), None,
+                                                   ptr(sums), ptr(scratch), stream), "fwd sparse")
+        else:
+            check(L.ggs_photometric_forward_roi(V, H, W, ptr(img), ptr(gt), ptr(mask), None, None, ptr(tc), ptr(sums),
+                                                ptr(scratch), stream), "fwd roi")
+        d = torch.full((V, 3, H, W), 123.0, device=dev)
+        check(L.ggs_photometric_backward_roi(V, H, W, ptr(img), ptr(gt), ptr(mask), None, None, ptr(tc), ptr(scratch),
+                                             ptr(w), ptr(d), stream), "bwd")
+        return sums, d
+
+    s_roi, d_roi = run(False)
+    for table in (False, True):
+        s_sp, d_sp = run(True, table)
+        assert float((s_roi - s_sp).abs().max()) <= 2e-6 * float(s_roi.abs().max()), (s_roi, s_sp)
+        assert torch.equal(d_roi, d_sp)                              # incl. the 123s of the boxes nobody writes
+    assert torch.isfinite(d_roi).all()
+    # and against the PyTorch restatement of the reference's loss
+    from ggsplat.loss import l1_loss, ssim
+    for v in range(V):
+        want_l1 = float(l1_loss(img[v], gt[v], mask[v])) * 3 * H * W
+        want_ss = float(ssim(img[v].clone(), gt[v].clone(), mask[v])) * 3 * H * W
+        assert abs(float(s_sp[v, 0]) - want_l1) <= 1e-4 * max(want_l1, 1.0)
+        assert abs(float(s_sp[v, 1]) - want_ss) <= 2e-5 * want_ss
+
+
+def test_sparse_mask_form_through_the_python_wrapper_and_its_errors():
+    from ggsplat._lib import GgsError, check, lib, ptr
+    from ggsplat.loss import fused_photometric_loss, mask_tile_occupancy
+    g = torch.Generator().manual_seed(11)
+    H, W = 120, 200
+    img = torch.rand(3, H, W, generator=g).cuda().requires_grad_(True)
+    gt = torch.rand(3, H, W, generator=g).cuda()
+    mask = _blob_mask(1, H, W, g, "disc")[0].cuda()
+    mt = mask_tile_occupancy(mask)
+    tc = (mt.reshape(1, -1) != 0).int()
+    outs = []
+    for tiles in (None, mt):
+        img.grad = None
+        a, b = fused_photometric_loss(img, gt, mask, 0.2, tile_count=tc, mask_tiles=tiles)
+        (a + b).backward()
+        outs.append((float(a), float(b), img.grad.clone()))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[0][0]) and abs(outs[0][1] - outs[1][1]) <= 1e-6 * abs(outs[0][1])
+    assert torch.equal(outs[0][2], outs[1][2])
+    with pytest.raises(ValueError, match="mask_tiles needs"):
+        fused_photometric_loss(img, gt, mask, 0.2, tile_count=None, mask_tiles=mt)
+    with pytest.raises(ValueError, match="mask_tiles needs"):
+        fused_photometric_loss(img, gt, None, 0.2, tile_count=tc, mask_tiles=mt)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        mask_tile_occupancy(mask.cpu())
+    # the C entry point refuses the combinations the wrapper refuses, and a missing table
+    L = lib()
+    sums = torch.empty(1, 2, device="cuda")
+    scratch = torch.empty(L.ggs_photometric_scratch_bytes(1, H, W), device="cuda", dtype=torch.uint8)
+    x = img.detach()
+    assert L.ggs_photometric_forward_sparse(1, H, W, ptr(x), ptr(gt), ptr(mask), None, None, None, ptr(mt), None, ptr(sums),
+                                            ptr(scratch), None) != 0
+    assert L.ggs_photometric_forward_sparse(1, H, W, ptr(x), ptr(gt), None, None, None, ptr(tc), ptr(mt), None, ptr(sums),
+                                            ptr(scratch), None) != 0
+    assert L.ggs_photometric_forward_sparse(1, H, W, ptr(x), ptr(gt), ptr(mask), None, None, ptr(tc), None, None, ptr(sums),
+                                            ptr(scratch), None) != 0
+    assert L.ggs_mask_tiles(1, H, W, None, ptr(mt), None) != 0 and L.ggs_mask_tiles(0, H, W, ptr(mask), ptr(mt), None) != 0
+
+
 def test_steps_with_the_region_of_interest_loss_give_the_same_gradients():
     """registration_step(fused_loss=True) now takes the loss gradient only where the render backward reads it: every parameter
     gradient equals the one obtained with the full dL/dimage (tile_count=None)."""

@@ -36,6 +36,9 @@ import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_
       for i in 1 2 3; do for f in $( [ -z "$LIBS" ] && echo gaussian-garments_amd/csrc/libggsplat.so || libs ); do echo -n "$(basename $f): "; GGS_LIB_PATH=$PWD/$f timeout 600 python tools/profile_graph_step.py 256 2>&1 | tail -1; done; done > $OUT/${TAG}_graphstep.txt; cat $OUT/${TAG}_graphstep.txt ;;
     pipestep)        # sequential vs pipelined replay of the captured s2 iteration (tools/profile_graph_step.py [--pipelined]), three interleaved runs
       for i in 1 2 3; do timeout 300 python tools/profile_graph_step.py 256 2>&1 | tail -1; timeout 300 python tools/profile_graph_step.py 256 --pipelined 2>&1 | tail -1; done > $OUT/${TAG}_pipestep.txt; cat $OUT/${TAG}_pipestep.txt ;;
+    sparsestep)      # captured s2 iteration with silhouette masks: sparse-mask loss pass against the plain one, sequential and pipelined
+      for i in 1 2 3; do for a in "--silhouette --plain-loss" "--silhouette" "--silhouette --plain-loss --pipelined" "--silhouette --pipelined" "--pipelined"; do
+        timeout 300 python tools/profile_graph_step.py 256 $a 2>&1 | tail -1; done; done > $OUT/${TAG}_sparsestep.txt; cat $OUT/${TAG}_sparsestep.txt ;;
     graphprof)       # kernel table of the graph-replayed s2 iteration (rocprofv3 --kernel-trace, last 60 periods)
       R=$PWD; (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/gs -o g -- python $R/tools/profile_graph_step.py 64 > $R/$OUT/gs.log 2>&1)
       python tools/rocpd_summary.py $(find $OUT/gs -name "*.db" | head -1) --cycles 60 --anchor ${ANCHOR:-k_adam_multi} > $OUT/${TAG}_graph_step_kernels.md 2>&1
