@@ -168,8 +168,13 @@ class MeshGaussianModel(DensifyMixin):
         reset_opacity, load_ply ...) and the grad mode -- a binding first evaluated under torch.no_grad() carries no
         graph and must not be handed to a later render() that needs gradients."""
         local = self.local_xyz if final else self._xyz
-        ins = (self.mesh.v, local, self._scaling, self._rotation, self.gs_bc, self.mesh.f, self.binding)
-        return (final, torch.is_grad_enabled()), ins, tuple(_version_of(t) for t in ins)
+        mesh = self.mesh
+        ins = (mesh.v, local, self._scaling, self._rotation, self.gs_bc, mesh.f, self.binding)
+        try:                    # (three calls per render(): the plain attribute read, not a function call per tensor)
+            vers = tuple([None if t is None else t._version for t in ins])
+        except RuntimeError:    # inference-mode tensors have no version counter
+            vers = tuple(_version_of(t) for t in ins)
+        return (final, torch.is_grad_enabled()), ins, vers
 
     def _bind(self, final: bool = False):
         mode, ins, vers = self._bind_key(final)

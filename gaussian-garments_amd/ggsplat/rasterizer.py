@@ -28,11 +28,16 @@ from ._lib import GgsParams, check, lib, ptr
 _cap_hint: Dict[Tuple, int] = {}
 
 
+def _header_of(binb: torch.Tensor) -> torch.Tensor:
+    return binb[:16].view(torch.int64)
+
+
 def last_header() -> Optional[torch.Tensor]:
     """Device int64[2] = GgsBinHeader {num_rendered, overflow} of the most recent forward ISSUED BY THE CALLING THREAD
     (aliases its workspace).  Per thread, like the pinned landing buffer: the guarded optimiser step of one thread must
     not read the overflow word of a forward that another thread (an eval worker) issued in between."""
-    return getattr(_pinned, "last_header", None)
+    b = getattr(_pinned, "last_bin", None)
+    return None if b is None else _header_of(b[0])
 
 
 def last_tile_count() -> Optional[torch.Tensor]:
@@ -168,7 +173,28 @@ def plan_step(P: int, K: int, sh_degree: int, W: int, H: int, V: int, dev) -> St
 class ForwardState:
     """Everything the backward needs (the reference keeps the same things in ctx)."""
     __slots__ = ("prm", "bg", "means3D", "shs", "colors", "opac", "scales", "rots", "cov", "view", "proj",
-                 "campos", "tanfov", "geom", "bin", "cap", "img", "num_rendered", "header")
+                 "campos", "tanfov", "geom", "bin", "cap", "img", "num_rendered", "bwd_args")
+
+    @property
+    def header(self) -> torch.Tensor:
+        """Device int64[2] {num_rendered, overflow} of THIS forward (a view into its binning buffer, made on demand: the
+        per-view loop never looks at it)."""
+        return _header_of(self.bin)
+
+
+_prm_cache: Dict[Tuple, GgsParams] = {}
+
+
+def _params(P: int, K: int, deg: int, W: int, H: int, V: int, scale_modifier: float, debug: int) -> GgsParams:
+    """The GgsParams block of a problem shape, built once (nothing writes to it after construction; a ctypes Structure
+    with nine fields costs ~3 us per call to fill)."""
+    k = (P, K, deg, W, H, V, scale_modifier, debug)
+    prm = _prm_cache.get(k)
+    if prm is None:
+        if len(_prm_cache) > 256:
+            _prm_cache.clear()
+        prm = _prm_cache[k] = GgsParams(P, K, deg, W, H, V, scale_modifier, 0, debug)
+    return prm
 
 
 def _prep_forward(means3D, opacities, shs, colors_precomp, scales, rotations, cov3D_precomp, view, proj, campos, tanfov, bg,
@@ -187,19 +213,30 @@ def _prep_forward(means3D, opacities, shs, colors_precomp, scales, rotations, co
             for t in (shs, colors_precomp, scales, rotations, cov3D_precomp))
     # camera tensors and background left on the host are moved (the kernels would dereference host pointers otherwise: a GPU
     # memory fault, not an exception); the reference keeps them on the device (scene/cameras.py ends every matrix in .cuda())
-    view, proj, campos, tanfov, bg = (t if t.device == dev else t.to(dev) for t in (view, proj, campos, tanfov, bg))
-    view = _f32c(view).reshape(-1, 16)
-    V = view.shape[0]
-    proj = _f32c(proj).reshape(V, 16)
-    campos = _f32c(campos).reshape(V, 3)
-    tanfov = _f32c(tanfov).reshape(V, 2)
-    bg = _f32c(bg)
-    if bg.numel() == 3:
-        bg = bg.reshape(1, 3) if V == 1 else bg.reshape(1, 3).expand(V, 3).contiguous()
+    di = dev.index
+    if not (view.get_device() == di and proj.get_device() == di and campos.get_device() == di and tanfov.get_device() == di
+            and bg.get_device() == di):
+        view, proj, campos, tanfov, bg = (t if t.device == dev else t.to(dev) for t in (view, proj, campos, tanfov, bg))
+    if view.numel() == 16 and bg.numel() == 3:
+        # one view (the per-camera loop of the reference): the kernels take pointers, so the camera blocks are handed on in
+        # whatever shape they have -- four reshapes and a background view per call were ~8 us of host time
+        V = 1
+        view, proj, campos, tanfov, bg = _f32c(view), _f32c(proj), _f32c(campos), _f32c(tanfov), _f32c(bg)
+        if proj.numel() != 16 or campos.numel() != 3 or tanfov.numel() != 2:
+            raise _lib.GgsError("ggsplat: one view needs proj [16], campos [3], tanfov [2]")
     else:
-        bg = bg.reshape(V, 3).contiguous()
+        view = _f32c(view).reshape(-1, 16)
+        V = view.shape[0]
+        proj = _f32c(proj).reshape(V, 16)
+        campos = _f32c(campos).reshape(V, 3)
+        tanfov = _f32c(tanfov).reshape(V, 2)
+        bg = _f32c(bg)
+        if bg.numel() == 3:
+            bg = bg.reshape(1, 3) if V == 1 else bg.reshape(1, 3).expand(V, 3).contiguous()
+        else:
+            bg = bg.reshape(V, 3).contiguous()
     K = shs.shape[1] if shs is not None else 0
-    prm = GgsParams(P, K, int(sh_degree), int(W), int(H), V, float(scale_modifier), 0, int(bool(debug)))
+    prm = _params(P, K, int(sh_degree), int(W), int(H), V, float(scale_modifier), int(bool(debug)))
 
     color = torch.empty(V, 3, H, W, device=dev, dtype=torch.float32)
     depth = torch.empty(V, H, W, device=dev, dtype=torch.float32)
@@ -223,28 +260,18 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
     key = (dev.index, P, W, H, V)
     cap = _cap_hint.get(key, max(8 * P * V, 1 << 16))
     stream = _lib.stream_ptr(dev)
-    host = _pinned_header(dev)
     geom = img = None
     ws = workspaces if (workspaces is not None and workspaces.key == key and workspaces.cap == cap) else None
     capturing = torch.cuda.is_current_stream_capturing()
-    while capturing:        # one pass: static capacity, no host sync, overflow flag left on the device
-        if key not in _cap_hint:
-            raise _lib.GgsError("ggsplat: run this configuration eagerly once before capturing it into a graph "
-                                "(the binning capacity is learnt from an eager call)")
-        gsz, isz, bsz = _workspace_sizes(L, prm, cap)
-        if ws is not None:
-            geom, img, binb = ws.geom, ws.img, ws.bin
-        else:
-            geom = torch.empty(gsz, device=dev, dtype=torch.uint8)
-            img = torch.empty(isz, device=dev, dtype=torch.uint8)
-            binb = torch.empty(bsz, device=dev, dtype=torch.uint8)
-        args = (C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales),
-                ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov), ptr(geom),
-                ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha), ptr(radii), stream)
-        check(L.ggs_forward(*args), "ggs_forward")
-        n = -1
-        break
-    while not capturing:
+    if capturing and key not in _cap_hint:
+        raise _lib.GgsError("ggsplat: run this configuration eagerly once before capturing it into a graph "
+                            "(the binning capacity is learnt from an eager call)")
+    # the device pointers of the inputs, taken once: the backward of this forward is handed the same ones (ForwardState.bwd_args)
+    p_in = (ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales), ptr(rotations),
+            ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov))
+    p_out = (ptr(color), ptr(depth), ptr(alpha), ptr(radii), stream)
+    prm_ref = C.byref(prm)
+    while True:
         gsz, isz, bsz = _workspace_sizes(L, prm, cap)
         if ws is not None and ws.cap == cap:          # (an overflow retry runs with a larger capacity and its own buffers)
             geom, img, binb = ws.geom, ws.img, ws.bin
@@ -254,35 +281,41 @@ def forward_views(means3D, opacities, shs, colors_precomp, scales, rotations, co
             if img is None or img.numel() < isz:
                 img = torch.empty(isz, device=dev, dtype=torch.uint8)
             binb = torch.empty(bsz, device=dev, dtype=torch.uint8)
-        args = (C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales),
-                ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov), ptr(geom),
-                ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha), ptr(radii), stream)
-        # phase 1: preprocess + tile histogram + scan; its 16-byte header {num_rendered, overflow} is copied out behind it.
-        # phase 2 (scatter + sort + composite) is queued right away, WITHOUT waiting for the header: every kernel of it is
-        # guarded by the overflow word on the device, so with the capacity learnt from earlier calls it is simply the
-        # render, and in the rare overflow case it composites nothing and the call is repeated with the exact size.  The
-        # ONLY host sync of the call waits for the header copy (~10 us of GPU work in front of it -- the same point where
-        # the upstream extension syncs to size its binning buffer) while the GPU is already compositing.
-        ev = _header_event(dev)
-        check(L.ggs_forward_spec(*args, host.data_ptr(), ev.cuda_event), "ggs_forward_spec")   # count | header copy + event | render
+        p_ws = (geom.data_ptr(), binb.data_ptr(), cap, img.data_ptr())
+        if capturing:       # one pass: static capacity, no host sync, overflow flag left on the device
+            check(L.ggs_forward(prm_ref, *p_in, *p_ws, *p_out), "ggs_forward")
+            n = -1
+        else:
+            # phase 1: preprocess + tile histogram + scan; its 16-byte header {num_rendered, overflow} is copied out behind it.
+            # phase 2 (scatter + sort + composite) is queued right away, WITHOUT waiting for the header: every kernel of it is
+            # guarded by the overflow word on the device, so with the capacity learnt from earlier calls it is simply the
+            # render, and in the rare overflow case it composites nothing and the call is repeated with the exact size.  The
+            # ONLY host sync of the call waits for the header copy (~10 us of GPU work in front of it -- the same point where
+            # the upstream extension syncs to size its binning buffer) while the GPU is already compositing.
+            host, ev = _pinned_header(dev), _header_event(dev)
+            check(L.ggs_forward_spec(prm_ref, *p_in, *p_ws, *p_out, host.data_ptr(), ev.cuda_event), "ggs_forward_spec")
+        # (what follows does not depend on the header: it runs while the GPU works through phase 1, the wait comes last)
+        _pinned.last_bin = (binb, V, _lib.n_tiles(W, H), _tile_count_offset(L, prm, cap))
+        st = None
+        if keep_state:
+            st = ForwardState()
+            st.prm, st.bg, st.means3D, st.shs, st.colors, st.opac = prm, bg, means3D, shs, colors_precomp, opacities
+            st.scales, st.rots, st.cov, st.view, st.proj, st.campos, st.tanfov = scales, rotations, cov3D_precomp, view, proj, campos, tanfov
+            st.geom, st.bin, st.cap, st.img = geom, binb, cap, img
+            # ggs_backward's leading arguments: (prm, bg, means3D, shs, colors, scales, rots, cov3D, view, proj, campos, tanfov,
+            # geom, bin, capacity, img) -- the state holds the tensors, so the addresses stay valid
+            st.bwd_args = (prm_ref,) + p_in[:4] + p_in[5:] + p_ws
+        if capturing:
+            _capture_headers.append(_header_of(binb))
+            break
         ev.synchronize()
-        n, overflow = int(host[0]), int(host[1])
+        n, overflow = host.tolist()
         if not overflow:
+            _cap_hint[key] = max(cap if n * 2 <= cap else int(n * 2), 1 << 16)
             break
         cap = int(n * 1.25) + 1024             # n is exact: one retry is always enough
-    if not capturing:
-        _cap_hint[key] = max(cap if n * 2 <= cap else int(n * 2), 1 << 16)
-    _last_header = _pinned.last_header = binb[:16].view(torch.int64)
-    _pinned.last_bin = (binb, V, _lib.n_tiles(W, H), _tile_count_offset(L, prm, cap))
-    if capturing:
-        _capture_headers.append(_last_header)
-    st = None
-    if keep_state:
-        st = ForwardState()
-        st.prm, st.bg, st.means3D, st.shs, st.colors, st.opac = prm, bg, means3D, shs, colors_precomp, opacities
-        st.scales, st.rots, st.cov, st.view, st.proj, st.campos, st.tanfov = scales, rotations, cov3D_precomp, view, proj, campos, tanfov
-        st.geom, st.bin, st.cap, st.img, st.num_rendered = geom, binb, cap, img, n
-        st.header = _last_header                      # device int64[2] {num_rendered, overflow} of THIS call
+    if st is not None:
+        st.num_rendered = n
     return color, radii, depth, alpha, st
 
 
@@ -311,11 +344,12 @@ class StagedForward:
         self._args = (C.byref(prm), ptr(bg), ptr(means3D), ptr(shs), ptr(colors_precomp), ptr(opacities), ptr(scales),
                       ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov), ptr(geom),
                       ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha), ptr(radii))
-        self.header = binb[:16].view(torch.int64)
+        self.header = _header_of(binb)
         st = self.state = ForwardState()
         st.prm, st.bg, st.means3D, st.shs, st.colors, st.opac = prm, bg, means3D, shs, colors_precomp, opacities
         st.scales, st.rots, st.cov, st.view, st.proj, st.campos, st.tanfov = scales, rotations, cov3D_precomp, view, proj, campos, tanfov
-        st.geom, st.bin, st.cap, st.img, st.num_rendered, st.header = geom, binb, cap, img, -1, self.header
+        st.geom, st.bin, st.cap, st.img, st.num_rendered = geom, binb, cap, img, -1
+        st.bwd_args = self._args[:5] + self._args[6:17]
         if torch.cuda.is_current_stream_capturing():
             _capture_headers.append(self.header)
 
@@ -365,12 +399,12 @@ def backward_views(st: ForwardState, dL_dcolor, dL_ddepth=None, dL_dalpha=None, 
         nbytes = _bwd_scratch[k] = int(L.ggs_backward_scratch_bytes(C.byref(prm)))
     if scratch is None or scratch.numel() < nbytes:
         scratch = torch.empty(nbytes, device=dev, dtype=torch.uint8)
-    check(L.ggs_backward(C.byref(prm), ptr(st.bg), ptr(st.means3D), ptr(st.shs), ptr(st.colors), ptr(st.scales),
-                         ptr(st.rots), ptr(st.cov), ptr(st.view), ptr(st.proj), ptr(st.campos), ptr(st.tanfov),
-                         ptr(st.geom), ptr(st.bin), st.cap, ptr(st.img), ptr(dL_dcolor), ptr(dL_ddepth),
-                         ptr(dL_dalpha), ptr(scratch), ptr(g.get("means2D") if want_means2D else None),
-                         ptr(g["means3D"]), ptr(g["opacities"]), ptr(g.get("shs")), ptr(g.get("colors_precomp")),
-                         ptr(g.get("scales")), ptr(g.get("rotations")), ptr(g.get("cov3D_precomp")),
+    gg = g.get
+    # (prm, inputs, workspaces): the addresses the forward of this state was called with
+    check(L.ggs_backward(*st.bwd_args, ptr(dL_dcolor), ptr(dL_ddepth),
+                         ptr(dL_dalpha), scratch.data_ptr(), ptr(gg("means2D") if want_means2D else None),
+                         ptr(g["means3D"]), ptr(g["opacities"]), ptr(gg("shs")), ptr(gg("colors_precomp")),
+                         ptr(gg("scales")), ptr(gg("rotations")), ptr(gg("cov3D_precomp")),
                          int(bool(accumulate)), _stream_ptr(dev)), "ggs_backward")
     return g
 
