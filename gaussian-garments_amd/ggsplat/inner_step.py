@@ -280,13 +280,20 @@ class GraphedRegistrationStep:
 
     def _tiles_of(self, m):
         """Tile occupancy of mask tensor `m` (ggs_mask_tiles), computed once per (tensor, version); the first one also settles
-        sparse_mask=None: sparse iff fewer than half of the tiles hold a mask pixel (one read-back, once)."""
+        sparse_mask=None: sparse iff fewer than half of the tiles hold a mask pixel (one read-back, once).  The cache holds
+        the masks by WEAK reference: a caller that uploads a fresh mask every iteration (`gt_mask.cuda()`, as the reference's
+        loop does with its images) must not find 8 MB per iteration kept alive here."""
+        import weakref
         from .loss import mask_tile_occupancy
-        ent = self._mask_tiles.get(id(m))
-        if ent is None or ent[0] is not m or ent[1] != m._version:
-            if len(self._mask_tiles) > 4096:
-                self._mask_tiles.clear()
-            ent = self._mask_tiles[id(m)] = (m, m._version, mask_tile_occupancy(m))
+        cache = self._mask_tiles
+        ent = cache.get(id(m))
+        if ent is None or ent[0]() is not m or ent[1] != m._version:
+            if len(cache) > 256:
+                for k in [k for k, e in cache.items() if e[0]() is None]:
+                    del cache[k]
+                if len(cache) > 4096:
+                    cache.clear()
+            ent = cache[id(m)] = (weakref.ref(m), m._version, mask_tile_occupancy(m))
         if self._sparse is None:
             t = ent[2]
             self._sparse = bool(int((t != 0).sum()) * 2 < t.numel())

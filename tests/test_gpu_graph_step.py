@@ -517,6 +517,15 @@ def test_lean_step_with_the_sparse_mask_loss_gives_the_same_trajectory(pipelined
         if pa.numel():
             ok = (pa.detach() - pb.detach()).abs() <= 2e-6 + 1e-4 * pa.detach().abs()
             assert float(ok.float().mean()) >= 0.995 and float((pa.detach() - pb.detach()).abs().mean()) <= 1e-5
+    # masks uploaded afresh every iteration are not kept alive by the tile-table cache (weak references)
+    import gc
+    for _ in range(6):
+        sparse(cams[0], gts[0], masks[0].clone())
+    if pipelined:
+        sparse.flush()
+    gc.collect()
+    alive = sum(e[0]() is not None for e in firsts[1]._mask_tiles.values())
+    assert alive <= len(set(order)) + 2, alive
     # a dense mask settles sparse_mask=None the other way
     d = GraphedRegistrationStep(_model(v, f, params, opt, True), W, H, bg, opt=opt)
     d(cams[0], gts[0], dense_masks[0])
