@@ -191,6 +191,42 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
 }
 
 
+// The walk of the latency mapping takes the entries that reach its quadrant two at a time.
+struct PairSel { int j, jb; bool useB; };
+struct PairRec { float4 a0, a1, b0, b1; float a2x, a2y, b2x, b2y; };
+struct PairAlpha { float alA, alB; uint64_t okA, okB; };
+// next two set bits of `todo` (removed from it); an exhausted mask gives slot 0 / no B
+__device__ __forceinline__ PairSel pick_pair(uint64_t& todo) {
+    PairSel s;
+    s.j = todo ? __builtin_ctzll(todo) : 0;
+    todo &= todo - 1;
+    s.useB = todo != 0;
+    s.jb = s.useB ? __builtin_ctzll(todo) : s.j;
+    todo &= todo - 1;                                      // (0 & -1 = 0 when B does not exist)
+    return s;
+}
+__device__ __forceinline__ PairRec load_pair(const float4* s_rec, const PairSel& s) {
+    PairRec r;
+    r.a0 = s_rec[s.j * 3 + 0]; r.a1 = s_rec[s.j * 3 + 1];
+    r.b0 = s_rec[s.jb * 3 + 0]; r.b1 = s_rec[s.jb * 3 + 1];
+    const float2 a2 = *reinterpret_cast<const float2*>(s_rec + s.j * 3 + 2), b2 = *reinterpret_cast<const float2*>(s_rec + s.jb * 3 + 2);
+    r.a2x = a2.x; r.a2y = a2.y; r.b2x = b2.x; r.b2y = b2.y;
+    return r;
+}
+// both alpha tests (independent of T and of each other); a missing B passes nowhere
+__device__ __forceinline__ PairAlpha test_pair(const PairRec& r, float pxf, float pyf, bool useB) {
+    PairAlpha p;
+    const float dxA = r.a0.x - pxf, dyA = r.a0.y - pyf, dxB = r.b0.x - pxf, dyB = r.b0.y - pyf;
+    const float pA = ggs_falloff_log2(r.a0.z, r.a0.w, r.a1.x, dxA, dyA);
+    const float pB = ggs_falloff_log2(r.b0.z, r.b0.w, r.b1.x, dxB, dyB);
+    p.alA = __builtin_fminf(GGS_ALPHA_MAX, r.a1.y * __builtin_amdgcn_exp2f(pA));
+    p.alB = __builtin_fminf(GGS_ALPHA_MAX, r.b1.y * __builtin_amdgcn_exp2f(pB));
+    p.okA = __builtin_amdgcn_ballot_w64(pA <= 0.f) & __builtin_amdgcn_ballot_w64(p.alA >= GGS_ALPHA_MIN);
+    p.okB = __builtin_amdgcn_ballot_w64(pB <= 0.f) & __builtin_amdgcn_ballot_w64(p.alB >= GGS_ALPHA_MIN);
+    if (!useB) p.okB = 0;
+    return p;
+}
+
 // K4b body, latency mapping (one wave per (tile, quadrant), launches too small to fill the chip).  A wave that has
 // its SIMD almost to itself spends most of each splat waiting: LDS record read -> 9 dependent VALU ops of the alpha
 // test -> blend.  Two consecutive splats are therefore tested together (independent chains, both records read up
@@ -214,11 +250,12 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
         }
     }
     const bool inside = px < a.W && py < a.H;
-    float pxf = inside ? (float)px : inf_v;
+    const float pxf = inside ? (float)px : inf_v;
     const float pyf = (float)py;
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
     uint32_t last = 0;
-    int remaining = (int)__popcll(__builtin_amdgcn_ballot_w64(inside));
+    uint64_t dead = ~__builtin_amdgcn_ballot_w64(inside);          // pixels outside the image, later also the finished ones
+    int remaining = 64 - (int)__popcll(dead);
     const uint32_t mine = 1u << (GGS_ID_BITS + q0);
 
     __shared__ float4 s_rec[64 * 3];
@@ -238,73 +275,66 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
             // never touches the others (about half of a tile's list)
             uint64_t todo = __builtin_amdgcn_ballot_w64((cur.w & mine) != 0);
             if (n < 64) todo &= (1ull << n) - 1ull;
-            while (todo != 0 && remaining != 0) {
-                const int j = __builtin_ctzll(todo);
-                todo &= todo - 1;
-                const bool useA = true, useB = todo != 0;
-                const int jb = useB ? __builtin_ctzll(todo) : j;
-                todo &= todo - 1;                                  // (0 & -1 = 0 when B does not exist)
-                const float4 a0 = s_rec[j * 3 + 0], a1 = s_rec[j * 3 + 1], a2 = s_rec[j * 3 + 2];
-                const float4 b0 = s_rec[jb * 3 + 0], b1 = s_rec[jb * 3 + 1], b2 = s_rec[jb * 3 + 2];
-                // both alpha tests (independent of T and of each other)
-                const float dxA = a0.x - pxf, dyA = a0.y - pyf, dxB = b0.x - pxf, dyB = b0.y - pyf;
-                const float pA = ggs_falloff_log2(a0.z, a0.w, a1.x, dxA, dyA);
-                const float pB = ggs_falloff_log2(b0.z, b0.w, b1.x, dxB, dyB);
-                const float alA = __builtin_fminf(GGS_ALPHA_MAX, a1.y * __builtin_amdgcn_exp2f(pA));
-                const float alB = __builtin_fminf(GGS_ALPHA_MAX, b1.y * __builtin_amdgcn_exp2f(pB));
-                uint64_t okA = __builtin_amdgcn_ballot_w64(pA <= 0.f) & __builtin_amdgcn_ballot_w64(alA >= GGS_ALPHA_MIN);
-                uint64_t okB = __builtin_amdgcn_ballot_w64(pB <= 0.f) & __builtin_amdgcn_ballot_w64(alB >= GGS_ALPHA_MIN);
-                if (!useA) okA = 0;
-                if (!useB) okB = 0;
-                // Both blends run unconditionally (w = 0 in the lanes that do not take the entry): an entry that reaches the quadrant
-                // is blended by some pixel 99 times in 100, and a wave on its own pays ~7 cycles for EVERY instruction it issues --
-                // the branches around the blends and the register moves at their joins cost more than the rare skipped blend saves.
-                uint64_t stopA;
+            if (todo == 0) continue;
+            // SOFTWARE PIPELINE over the pairs of the round: while pair i is blended (a chain through T: multiply, subtract,
+            // compare, lane masks, select, subtract -- per entry) the records of pair i + 1 are on their way from the LDS and its
+            // two alpha tests (which depend on neither T nor on pair i) fill the issue slots the chain leaves.  A pixel that has
+            // finished is kept out by the scalar mask `dead`, not through its coordinate, so the tests of pair i + 1 need nothing
+            // that pair i produces.
+            // One step: start the loads of the next pair, blend the current one, test the next one.  The two register sets swap
+            // roles from step to step (the loop body is two steps), so nothing is copied at the back edge.
+            auto step = [&](const PairSel& sel_c, const PairRec& rc, const PairAlpha& pc, PairSel& sel_n, PairRec& rn,
+                            PairAlpha& pn) -> bool {
+                const bool more = todo != 0;
+                sel_n = pick_pair(todo);                             // (todo == 0: slot 0 twice, never used)
+                rn = load_pair(s_rec, sel_n);
+                // ---- blend A, then B (in list order)
+                const uint64_t okA = pc.okA & ~dead;
                 {
-                    const float wa = alA * T;
+                    const float wa = pc.alA * T;
                     const float test_T = T - wa;
-                    stopA = okA & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
-                    const uint64_t app = okA & ~stopA;
-                    if (stopA != 0) {                          // rare: a pixel finishes at most once
-                        asm volatile("" ::: "memory");
-                        remaining -= (int)__popcll(stopA);
-                        pxf = sel(stopA, inf_v, pxf);
-                    }
+                    const uint64_t stop = okA & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
+                    const uint64_t app = okA & ~stop;
+                    dead |= stop;
                     const float w = sel_or_zero(app, wa);
-                    C0 = fmaf(a1.z, w, C0); C1 = fmaf(a1.w, w, C1); C2 = fmaf(a2.x, w, C2); D = fmaf(a2.y, w, D);
+                    C0 = fmaf(rc.a1.z, w, C0); C1 = fmaf(rc.a1.w, w, C1); C2 = fmaf(rc.a2x, w, C2); D = fmaf(rc.a2y, w, D);
                     A += w; T -= w;
                     uint32_t posv;
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + j + 1));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + sel_c.j + 1));
                     last = __float_as_uint(sel(app, __uint_as_float(posv), __uint_as_float(last)));
                 }
-                if (okA == 0) {                                  // rare: nobody in this quadrant takes the entry
-                    asm volatile("" ::: "memory");
-                    if (lane == 0) atomicAnd(&ids[first + j], ~mine);    // four waves share the word: clear only this quadrant's bit
-                }
-                okB &= ~stopA;                                   // a pixel that stopped at A no longer takes B
-                if (remaining == 0) okB = 0;
+                const uint64_t okB = pc.okB & ~dead;                 // a pixel that stopped at A no longer takes B
                 {
-                    const float wa = alB * T;
+                    const float wa = pc.alB * T;
                     const float test_T = T - wa;
                     const uint64_t stop = okB & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
                     const uint64_t app = okB & ~stop;
-                    if (stop != 0) {
-                        asm volatile("" ::: "memory");
-                        remaining -= (int)__popcll(stop);
-                        pxf = sel(stop, inf_v, pxf);
-                    }
+                    dead |= stop;
                     const float w = sel_or_zero(app, wa);
-                    C0 = fmaf(b1.z, w, C0); C1 = fmaf(b1.w, w, C1); C2 = fmaf(b2.x, w, C2); D = fmaf(b2.y, w, D);
+                    C0 = fmaf(rc.b1.z, w, C0); C1 = fmaf(rc.b1.w, w, C1); C2 = fmaf(rc.b2x, w, C2); D = fmaf(rc.b2y, w, D);
                     A += w; T -= w;
                     uint32_t posv;
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + jb + 1));
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + sel_c.jb + 1));
                     last = __float_as_uint(sel(app, __uint_as_float(posv), __uint_as_float(last)));
                 }
-                if (useB && okB == 0) {                          // as before: not taken (or no longer taken) here -> clear the bit
+                // ---- the alpha tests of the next pair (independent of everything above)
+                pn = test_pair(rn, pxf, pyf, sel_n.useB);
+                // rare: nobody in this quadrant takes (or still takes) an entry -> clear this quadrant's bit of its id word (four
+                // waves share the word)
+                if (okA == 0 || (sel_c.useB && okB == 0)) {
                     asm volatile("" ::: "memory");
-                    if (lane == 0) atomicAnd(&ids[first + jb], ~mine);
+                    if (lane == 0) {
+                        if (okA == 0) atomicAnd(&ids[first + sel_c.j], ~mine);
+                        if (sel_c.useB && okB == 0) atomicAnd(&ids[first + sel_c.jb], ~mine);
+                    }
                 }
-            }
+                remaining = 64 - (int)__popcll(dead);
+                return more && remaining != 0;
+            };
+            PairSel s0 = pick_pair(todo), s1;
+            PairRec r0 = load_pair(s_rec, s0), r1;
+            PairAlpha p0 = test_pair(r0, pxf, pyf, s0.useB), p1;
+            while (step(s0, r0, p0, s1, r1, p1) && step(s1, r1, p1, s0, r0, p0)) {}
         }
     }
     if (!inside) return;
