@@ -191,30 +191,23 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
 }
 
 
-// The walk of the latency mapping takes the entries that reach its quadrant two at a time.
-struct PairSel { int j, jb; bool useB; };
-struct PairRec { float4 a0, a1, b0, b1; float a2x, a2y, b2x, b2y; };
+// The walk of the latency mapping takes the entries that reach its quadrant two at a time.  The records of a round are parked
+// in the LDS COMPACTED to those entries (slot = rank among them), each with its 1-based list position in the spare field c.z: the
+// walk is then a counter over the slots -- on a wave that has its SIMD to itself every instruction costs issue time, the scalar
+// ones too, and picking the next two set bits out of a lane mask took ~20 of them per pair.
+struct PairRec { float4 a0, a1, b0, b1; float a2x, a2y, b2x, b2y, posA, posB; };
 struct PairAlpha { float alA, alB; uint64_t okA, okB; };
-// next two set bits of `todo` (removed from it); an exhausted mask gives slot 0 / no B
-__device__ __forceinline__ PairSel pick_pair(uint64_t& todo) {
-    PairSel s;
-    s.j = todo ? __builtin_ctzll(todo) : 0;
-    todo &= todo - 1;
-    s.useB = todo != 0;
-    s.jb = s.useB ? __builtin_ctzll(todo) : s.j;
-    todo &= todo - 1;                                      // (0 & -1 = 0 when B does not exist)
-    return s;
-}
-__device__ __forceinline__ PairRec load_pair(const float4* s_rec, const PairSel& s) {
+__device__ __forceinline__ PairRec load_pair(const float4* s_rec, int slot) {      // slots `slot`, `slot + 1`
     PairRec r;
-    r.a0 = s_rec[s.j * 3 + 0]; r.a1 = s_rec[s.j * 3 + 1];
-    r.b0 = s_rec[s.jb * 3 + 0]; r.b1 = s_rec[s.jb * 3 + 1];
-    const float2 a2 = *reinterpret_cast<const float2*>(s_rec + s.j * 3 + 2), b2 = *reinterpret_cast<const float2*>(s_rec + s.jb * 3 + 2);
-    r.a2x = a2.x; r.a2y = a2.y; r.b2x = b2.x; r.b2y = b2.y;
+    const float4* p = s_rec + slot * 3;
+    r.a0 = p[0]; r.a1 = p[1];
+    r.b0 = p[3]; r.b1 = p[4];
+    const float4 a2 = p[2], b2 = p[5];
+    r.a2x = a2.x; r.a2y = a2.y; r.posA = a2.z; r.b2x = b2.x; r.b2y = b2.y; r.posB = b2.z;
     return r;
 }
-// both alpha tests (independent of T and of each other); a missing B passes nowhere
-__device__ __forceinline__ PairAlpha test_pair(const PairRec& r, float pxf, float pyf, bool useB) {
+// both alpha tests (independent of T and of each other)
+__device__ __forceinline__ PairAlpha test_pair(const PairRec& r, float pxf, float pyf) {
     PairAlpha p;
     const float dxA = r.a0.x - pxf, dyA = r.a0.y - pyf, dxB = r.b0.x - pxf, dyB = r.b0.y - pyf;
     const float pA = ggs_falloff_log2(r.a0.z, r.a0.w, r.a1.x, dxA, dyA);
@@ -223,7 +216,6 @@ __device__ __forceinline__ PairAlpha test_pair(const PairRec& r, float pxf, floa
     p.alB = __builtin_fminf(GGS_ALPHA_MAX, r.b1.y * __builtin_amdgcn_exp2f(pB));
     p.okA = __builtin_amdgcn_ballot_w64(pA <= 0.f) & __builtin_amdgcn_ballot_w64(p.alA >= GGS_ALPHA_MIN);
     p.okB = __builtin_amdgcn_ballot_w64(pB <= 0.f) & __builtin_amdgcn_ballot_w64(p.alB >= GGS_ALPHA_MIN);
-    if (!useB) p.okB = 0;
     return p;
 }
 
@@ -270,24 +262,35 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
             const Rec3 cur = nxt;
             if (first + 64 < L) { nxt = gather_recs(rec, w_ahead); w_ahead = gather_ids(ids, first + 128, L, lane); }
             const int n = min(64, L - first);
-            lds.put(cur, lane);
-            // entries of the round that reach this quadrant, as a lane mask: the walk takes them two at a time and
-            // never touches the others (about half of a tile's list)
+            // entries of the round that reach this quadrant (about half of a tile's list), compacted into the LDS slice
             uint64_t todo = __builtin_amdgcn_ballot_w64((cur.w & mine) != 0);
             if (n < 64) todo &= (1ull << n) - 1ull;
             if (todo == 0) continue;
+            const int count = (int)__popcll(todo);
+            {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
+                __builtin_amdgcn_wave_barrier();
+                if ((todo >> lane) & 1ull) {
+                    const float4 c = make_float4(cur.c.x, cur.c.y, __uint_as_float((uint32_t)(first + lane + 1)), 0.f);
+                    s_rec[rank * 3 + 0] = cur.a; s_rec[rank * 3 + 1] = cur.b; s_rec[rank * 3 + 2] = c;
+                    // an odd count: the last entry once more behind itself -- the B half of the last pair is blended with weight
+                    // zero, and zero times whatever the slot held before (a NaN of an earlier kernel) would not be zero
+                    if (rank == count - 1 && count < 64) { s_rec[count * 3 + 0] = cur.a; s_rec[count * 3 + 1] = cur.b; s_rec[count * 3 + 2] = c; }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
             // SOFTWARE PIPELINE over the pairs of the round: while pair i is blended (a chain through T: multiply, subtract,
             // compare, lane masks, select, subtract -- per entry) the records of pair i + 1 are on their way from the LDS and its
-            // two alpha tests (which depend on neither T nor on pair i) fill the issue slots the chain leaves.  A pixel that has
-            // finished is kept out by the scalar mask `dead`, not through its coordinate, so the tests of pair i + 1 need nothing
-            // that pair i produces.
-            // One step: start the loads of the next pair, blend the current one, test the next one.  The two register sets swap
-            // roles from step to step (the loop body is two steps), so nothing is copied at the back edge.
-            auto step = [&](const PairSel& sel_c, const PairRec& rc, const PairAlpha& pc, PairSel& sel_n, PairRec& rn,
-                            PairAlpha& pn) -> bool {
-                const bool more = todo != 0;
-                sel_n = pick_pair(todo);                             // (todo == 0: slot 0 twice, never used)
-                rn = load_pair(s_rec, sel_n);
+            // two alpha tests (which depend on neither T nor on pair i) run beside the chain.  A pixel that has finished is kept
+            // out by the scalar mask `dead`, not through its coordinate, so the tests of pair i + 1 need nothing that pair i
+            // produces.  One step: start the loads of the next pair, blend the current one, test the next one.  The two register
+            // sets swap roles from step to step (the loop body is two steps), so nothing is copied at the back edge.
+            // (Slots past `count` + 1 hold stale records: read, tested, never blended.)
+            int slot = 0;
+            auto step = [&](const PairRec& rc, const PairAlpha& pc, PairRec& rn, PairAlpha& pn) -> bool {
+                const bool hasB = slot + 1 < count;
+                const bool more = slot + 2 < count;
+                rn = load_pair(s_rec, (slot + 2) & 62);
                 // ---- blend A, then B (in list order)
                 const uint64_t okA = pc.okA & ~dead;
                 {
@@ -299,11 +302,9 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
                     const float w = sel_or_zero(app, wa);
                     C0 = fmaf(rc.a1.z, w, C0); C1 = fmaf(rc.a1.w, w, C1); C2 = fmaf(rc.a2x, w, C2); D = fmaf(rc.a2y, w, D);
                     A += w; T -= w;
-                    uint32_t posv;
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + sel_c.j + 1));
-                    last = __float_as_uint(sel(app, __uint_as_float(posv), __uint_as_float(last)));
+                    last = __float_as_uint(sel(app, rc.posA, __uint_as_float(last)));
                 }
-                const uint64_t okB = pc.okB & ~dead;                 // a pixel that stopped at A no longer takes B
+                const uint64_t okB = hasB ? pc.okB & ~dead : 0;      // a pixel that stopped at A no longer takes B
                 {
                     const float wa = pc.alB * T;
                     const float test_T = T - wa;
@@ -313,28 +314,28 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
                     const float w = sel_or_zero(app, wa);
                     C0 = fmaf(rc.b1.z, w, C0); C1 = fmaf(rc.b1.w, w, C1); C2 = fmaf(rc.b2x, w, C2); D = fmaf(rc.b2y, w, D);
                     A += w; T -= w;
-                    uint32_t posv;
-                    asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + sel_c.jb + 1));
-                    last = __float_as_uint(sel(app, __uint_as_float(posv), __uint_as_float(last)));
+                    last = __float_as_uint(sel(app, rc.posB, __uint_as_float(last)));
                 }
                 // ---- the alpha tests of the next pair (independent of everything above)
-                pn = test_pair(rn, pxf, pyf, sel_n.useB);
+                pn = test_pair(rn, pxf, pyf);
                 // rare: nobody in this quadrant takes (or still takes) an entry -> clear this quadrant's bit of its id word (four
                 // waves share the word)
-                if (okA == 0 || (sel_c.useB && okB == 0)) {
+                if (okA == 0 || (hasB && okB == 0)) {
                     asm volatile("" ::: "memory");
+                    const int ia = (int)__builtin_amdgcn_readfirstlane(__float_as_uint(rc.posA)) - 1;
+                    const int ib = (int)__builtin_amdgcn_readfirstlane(__float_as_uint(rc.posB)) - 1;
                     if (lane == 0) {
-                        if (okA == 0) atomicAnd(&ids[first + sel_c.j], ~mine);
-                        if (sel_c.useB && okB == 0) atomicAnd(&ids[first + sel_c.jb], ~mine);
+                        if (okA == 0) atomicAnd(&ids[ia], ~mine);
+                        if (hasB && okB == 0) atomicAnd(&ids[ib], ~mine);
                     }
                 }
+                slot += 2;
                 remaining = 64 - (int)__popcll(dead);
                 return more && remaining != 0;
             };
-            PairSel s0 = pick_pair(todo), s1;
-            PairRec r0 = load_pair(s_rec, s0), r1;
-            PairAlpha p0 = test_pair(r0, pxf, pyf, s0.useB), p1;
-            while (step(s0, r0, p0, s1, r1, p1) && step(s1, r1, p1, s0, r0, p0)) {}
+            PairRec r0 = load_pair(s_rec, 0), r1;
+            PairAlpha p0 = test_pair(r0, pxf, pyf), p1;
+            while (step(r0, p0, r1, p1) && step(r1, p1, r0, p0)) {}
         }
     }
     if (!inside) return;

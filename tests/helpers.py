@@ -35,3 +35,14 @@ def seeded_image_weights(W, H, seed=11):
     g = torch.Generator().manual_seed(seed)
     return (torch.randn(3, H, W, generator=g), torch.randn(1, H, W, generator=g) * 0.3,
             torch.randn(1, H, W, generator=g))
+
+
+def poison_lds():
+    """Leave NaNs in the LDS of (most of) the chip: sort / scan kernels of NaN-filled tensors stage their data there, and the
+    LDS is not cleared between kernels.  A kernel of this repo that multiplies a stale LDS word by a zero weight shows up as
+    NaN in its outputs -- only then, so run this right before the launch under test."""
+    import torch
+    x = torch.full((1024, 2048), float("nan"), device="cuda")
+    torch.sort(x, dim=1)
+    torch.cumsum(x, dim=1)
+    torch.cuda.synchronize()

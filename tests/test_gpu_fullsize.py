@@ -139,8 +139,12 @@ def test_latency_mapping_equals_throughput_mapping_bitwise(scene):
     P = inp["means3D"].shape[0]
     col = torch.rand(P, 3, generator=torch.Generator().manual_seed(6)).cuda()
     rep = {k: v[2:3].expand(8, *v.shape[1:]).contiguous() for k, v in ck.items()}        # the same camera 8 times
+    from helpers import poison_lds
+    poison_lds()                        # (stale LDS words must not reach the outputs: the walks park their records there)
     c8, r8, d8, a8, st8 = _fwd(inp, rep, colors=col, bg=(0.1, 0.2, 0.3), keep=True)
+    poison_lds()
     c1, r1, d1, a1, st1 = _fwd(inp, ck, colors=col, bg=(0.1, 0.2, 0.3), keep=True, views=slice(2, 3))
+    assert torch.isfinite(c1).all() and torch.isfinite(c8).all()
     assert torch.equal(c1[0], c8[5]) and torch.equal(d1[0], d8[5]) and torch.equal(a1[0], a8[5]) and torch.equal(r1[0], r8[5])
     s1, s8 = R.img_sections(st1), R.img_sections(st8)
     assert torch.equal(s1["final_T"][0], s8["final_T"][5]) and torch.equal(s1["n_contrib"][0], s8["n_contrib"][5])
