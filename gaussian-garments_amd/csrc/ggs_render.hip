@@ -247,7 +247,6 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
     float T = 1.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, D = 0.f, A = 0.f;
     uint32_t last = 0;
     uint64_t dead = ~__builtin_amdgcn_ballot_w64(inside);          // pixels outside the image, later also the finished ones
-    int remaining = 64 - (int)__popcll(dead);
     const uint32_t mine = 1u << (GGS_ID_BITS + q0);
 
     __shared__ float4 s_rec[64 * 3];
@@ -258,7 +257,7 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
         // waves to run meanwhile and only pays for the extra register: left as it is)
         Rec3 nxt = gather_round(rec, ids, 0, L, lane);
         uint32_t w_ahead = gather_ids(ids, 64, L, lane);
-        for (int first = 0; first < L && remaining != 0; first += 64) {
+        for (int first = 0; first < L && dead != ~0ull; first += 64) {
             const Rec3 cur = nxt;
             if (first + 64 < L) { nxt = gather_recs(rec, w_ahead); w_ahead = gather_ids(ids, first + 128, L, lane); }
             const int n = min(64, L - first);
@@ -273,9 +272,12 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
                 if ((todo >> lane) & 1ull) {
                     const float4 c = make_float4(cur.c.x, cur.c.y, __uint_as_float((uint32_t)(first + lane + 1)), 0.f);
                     s_rec[rank * 3 + 0] = cur.a; s_rec[rank * 3 + 1] = cur.b; s_rec[rank * 3 + 2] = c;
-                    // an odd count: the last entry once more behind itself -- the B half of the last pair is blended with weight
-                    // zero, and zero times whatever the slot held before (a NaN of an earlier kernel) would not be zero
-                    if (rank == count - 1 && count < 64) { s_rec[count * 3 + 0] = cur.a; s_rec[count * 3 + 1] = cur.b; s_rec[count * 3 + 2] = c; }
+                    // an odd count: a filler behind the last entry -- that entry again with opacity 0, so that it fails the alpha test
+                    // in every pixel and is blended with weight zero (zero times whatever the slot held before -- a NaN of an
+                    // earlier kernel -- would not be zero)
+                    if (rank == count - 1 && count < 64) {
+                        s_rec[count * 3 + 0] = cur.a; s_rec[count * 3 + 1] = make_float4(cur.b.x, 0.f, cur.b.z, cur.b.w); s_rec[count * 3 + 2] = c;
+                    }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -287,55 +289,69 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
             // sets swap roles from step to step (the loop body is two steps), so nothing is copied at the back edge.
             // (Slots past `count` + 1 hold stale records: read, tested, never blended.)
             int slot = 0;
-            auto step = [&](const PairRec& rc, const PairAlpha& pc, PairRec& rn, PairAlpha& pn) -> bool {
-                const bool hasB = slot + 1 < count;
-                const bool more = slot + 2 < count;
-                rn = load_pair(s_rec, (slot + 2) & 62);
-                // ---- blend A, then B (in list order)
-                const uint64_t okA = pc.okA & ~dead;
-                {
-                    const float wa = pc.alA * T;
-                    const float test_T = T - wa;
-                    const uint64_t stop = okA & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
-                    const uint64_t app = okA & ~stop;
-                    dead |= stop;
-                    const float w = sel_or_zero(app, wa);
-                    C0 = fmaf(rc.a1.z, w, C0); C1 = fmaf(rc.a1.w, w, C1); C2 = fmaf(rc.a2x, w, C2); D = fmaf(rc.a2y, w, D);
-                    A += w; T -= w;
-                    last = __float_as_uint(sel(app, rc.posA, __uint_as_float(last)));
-                }
-                const uint64_t okB = hasB ? pc.okB & ~dead : 0;      // a pixel that stopped at A no longer takes B
-                {
-                    const float wa = pc.alB * T;
-                    const float test_T = T - wa;
-                    const uint64_t stop = okB & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
-                    const uint64_t app = okB & ~stop;
-                    dead |= stop;
-                    const float w = sel_or_zero(app, wa);
-                    C0 = fmaf(rc.b1.z, w, C0); C1 = fmaf(rc.b1.w, w, C1); C2 = fmaf(rc.b2x, w, C2); D = fmaf(rc.b2y, w, D);
-                    A += w; T -= w;
-                    last = __float_as_uint(sel(app, rc.posB, __uint_as_float(last)));
-                }
-                // ---- the alpha tests of the next pair (independent of everything above)
-                pn = test_pair(rn, pxf, pyf);
-                // rare: nobody in this quadrant takes (or still takes) an entry -> clear this quadrant's bit of its id word (four
-                // waves share the word)
-                if (okA == 0 || (hasB && okB == 0)) {
-                    asm volatile("" ::: "memory");
-                    const int ia = (int)__builtin_amdgcn_readfirstlane(__float_as_uint(rc.posA)) - 1;
-                    const int ib = (int)__builtin_amdgcn_readfirstlane(__float_as_uint(rc.posB)) - 1;
-                    if (lane == 0) {
-                        if (okA == 0) atomicAnd(&ids[ia], ~mine);
-                        if (hasB && okB == 0) atomicAnd(&ids[ib], ~mine);
-                    }
-                }
-                slot += 2;
-                remaining = 64 - (int)__popcll(dead);
-                return more && remaining != 0;
-            };
+            uint64_t taken = 0, bitA = 1;                       // bit s of `taken`: the entry in slot s was taken by some pixel
+            // (two plain exits per step instead of one combined condition: on the scalar unit a compare + branch each, where the
+            // combined form materialised both conditions as lane masks first)
+#define GGS_FWD_STEP(rc, pc, rn, pn)                                                                                           \
+            {                                                                                                                  \
+                rn = load_pair(s_rec, (slot + 2) & 62);                                                                        \
+                asm volatile("" ::: "memory");   /* the six reads stay whole and up here (else they are split and sunk to their uses) */ \
+                /* ---- blend A, then B (in list order) */                                                                    \
+                const uint64_t okA = pc.okA & ~dead;                                                                           \
+                {                                                                                                              \
+                    const float wa = pc.alA * T;                                                                               \
+                    const float test_T = T - wa;                                                                               \
+                    const uint64_t stop = okA & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);                               \
+                    const uint64_t app = okA & ~stop;                                                                          \
+                    dead |= stop;                                                                                              \
+                    const float w = sel_or_zero(app, wa);                                                                      \
+                    C0 = fmaf(rc.a1.z, w, C0); C1 = fmaf(rc.a1.w, w, C1); C2 = fmaf(rc.a2x, w, C2); D = fmaf(rc.a2y, w, D);    \
+                    A += w; T -= w;                                                                                            \
+                    last = __float_as_uint(sel(app, rc.posA, __uint_as_float(last)));                                          \
+                }                                                                                                              \
+                const uint64_t okB = pc.okB & ~dead;     /* a pixel that stopped at A no longer takes B */                     \
+                {                                                                                                              \
+                    const float wa = pc.alB * T;                                                                               \
+                    const float test_T = T - wa;                                                                               \
+                    const uint64_t stop = okB & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);                               \
+                    const uint64_t app = okB & ~stop;                                                                          \
+                    dead |= stop;                                                                                              \
+                    const float w = sel_or_zero(app, wa);                                                                      \
+                    C0 = fmaf(rc.b1.z, w, C0); C1 = fmaf(rc.b1.w, w, C1); C2 = fmaf(rc.b2x, w, C2); D = fmaf(rc.b2y, w, D);    \
+                    A += w; T -= w;                                                                                            \
+                    last = __float_as_uint(sel(app, rc.posB, __uint_as_float(last)));                                          \
+                }                                                                                                              \
+                /* ---- the alpha tests of the next pair (independent of everything above) */                                  \
+                pn = test_pair(rn, pxf, pyf);                                                                                  \
+                /* which of the two entries anybody in this quadrant took (see below the walk) */                              \
+                taken |= (okA != 0 ? bitA : 0ull) | (okB != 0 ? bitA << 1 : 0ull);                                             \
+                bitA <<= 2;                                                                                                    \
+                slot += 2;                                                                                                     \
+                if (slot >= count) break;                                                                                      \
+                if (dead == ~0ull) goto round_done;                                                                            \
+            }
             PairRec r0 = load_pair(s_rec, 0), r1;
             PairAlpha p0 = test_pair(r0, pxf, pyf), p1;
-            while (step(r0, p0, r1, p1) && step(r1, p1, r0, p0)) {}
+            for (;;) {
+                GGS_FWD_STEP(r0, p0, r1, p1)
+                GGS_FWD_STEP(r1, p1, r0, p0)
+            }
+#undef GGS_FWD_STEP
+        round_done:
+            // An entry that reached the quadrant and passed the alpha test in none of its live pixels (about one in three: the
+            // binning tests the splat's ellipse against the quadrant's box, the pixels sample it) loses this quadrant's bit in its id
+            // word, so that the backward skips it here.  ONE vector atomic per round, issued by the lanes that hold such an entry
+            // (four waves share the word, each clears its own bit) -- as a scalar branch + a lane-0 atomic per entry this was a
+            // fifth of the walk's instructions.  Entries behind the point where the last pixel finished keep their bits: the
+            // backward stops at the last contributor.
+            {
+                const int visited = min(slot, count);
+                const uint64_t seen = visited >= 64 ? ~0ull : (1ull << visited) - 1ull;
+                const uint64_t drop = seen & ~taken;                                     // by slot
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
+                if (((todo >> lane) & 1ull) && ((drop >> rank) & 1ull)) atomicAnd(&ids[first + lane], ~mine);
+            }
+            if (dead == ~0ull) break;
         }
     }
     if (!inside) return;
