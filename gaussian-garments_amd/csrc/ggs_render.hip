@@ -448,6 +448,7 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
     __shared__ float4 s_rec[64 * 3];
     RoundLds lds{s_rec};
     __shared__ float s_red[8 * GGS_RED_STRIDE];
+    __shared__ float s_red2[NQ == 1 ? 8 * GGS_RED_STRIDE : 1];          // second plane: the pair reductions of the latency mapping
     // The nine per-entry sums start from zero: nine v_mov per list entry on the pipe that bounds this kernel.  Three broadcast
     // LDS reads of a zeroed slot deliver the same zeros on the LDS pipe, right behind the record reads the entry waits for anyway.
     __shared__ float4 s_zero[2];
@@ -462,40 +463,54 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
         if (r > 0) nxt = gather_round(rec, ids, (r - 1) * 64, L, lane);
         const int first = r * 64;
         const int n = min(64, maxc - first);
-        lds.put(cur, lane);
         // Entries of the round the forward blended somewhere in this wave's pixels, as a lane mask (lane i holds entry i):
-        // the walk jumps from set bit to set bit on the scalar unit, so an entry that is not ours (21 % of a tile's
-        // list, 63 % for a per-quadrant wave) costs nothing -- not even the LDS latency of reading its id word.
+        // an entry that is not ours (21 % of a tile's list, 63 % for a per-quadrant wave) costs nothing -- not even the LDS
+        // latency of reading its id word.
         uint64_t todo = __builtin_amdgcn_ballot_w64((cur.w & my_bits) != 0);
         if (n < 64) todo &= (1ull << n) - 1ull;
         if constexpr (NQ == 1) {
             // Latency mapping: two entries per iteration.  Their falloff / alpha evaluations, colour dot products and
             // the two gradient reductions are independent chains the scheduler interleaves; only the (T, B)
             // recurrence is sequential (A = the entry further back, then B).
-            auto reduce_add = [&](uint32_t word, float v_mx, float v_my, float v_cx, float v_cy, float v_cz, float v_op,
+            // The records are parked in the LDS COMPACTED to our entries, BACK TO FRONT (slot 0 = the last one), each with its
+            // list position and Gaussian id in the spare fields c.z / c.w, so that the walk is a slot counter: picking the two
+            // highest set bits out of the lane mask and reading their id words across lanes was ~15 scalar + 2 VALU instructions
+            // per pair on a wave that pays issue time for every one of them (as in render_fwd_quadwave).
+            const int count = (int)__popcll(todo);
+            if (count == 0) continue;
+            {
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
+                __builtin_amdgcn_wave_barrier();
+                if ((todo >> lane) & 1ull) {
+                    const int sl = count - 1 - rank;
+                    const float4 c = make_float4(cur.c.x, cur.c.y, __uint_as_float((uint32_t)(first + lane)),
+                                                 __uint_as_float(cur.w & GGS_ID_MASK));
+                    s_rec[sl * 3 + 0] = cur.a; s_rec[sl * 3 + 1] = cur.b; s_rec[sl * 3 + 2] = c;
+                    // an odd count: a filler behind the last slot (finite values; its B half is never reduced)
+                    if (rank == 0 && count < 64) { s_rec[count * 3 + 0] = cur.a; s_rec[count * 3 + 1] = cur.b; s_rec[count * 3 + 2] = c; }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            auto reduce_add = [&](uint32_t gid, float v_mx, float v_my, float v_cx, float v_cy, float v_cz, float v_op,
                                   float v_r, float v_g, float v_b, float v_dep) {
                 const float S = lds_transpose_reduce<DA>(s_red, lane, v_mx, v_my, v_cx, v_cy, v_cz, v_op, v_r, v_g, v_b, v_dep);
-                float* dst = reinterpret_cast<float*>(acc + (word & GGS_ID_MASK));
+                float* dst = reinterpret_cast<float*>(acc + gid);
                 if (fld >= 0) atomicAdd(dst + fld, S);
             };
-            while (todo) {
-                const int jA = 63 - __builtin_clzll(todo);
-                todo &= ~(1ull << jA);
-                const bool hasB = todo != 0;
-                const int jB = hasB ? 63 - __builtin_clzll(todo) : jA;
-                if (hasB) todo &= ~(1ull << jB);
-                const uint32_t wordA = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, jA);
-                const uint32_t wordB = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, jB);
-                const float4 a0 = s_rec[jA * 3 + 0], a1 = s_rec[jA * 3 + 1], a2 = s_rec[jA * 3 + 2];
-                const float4 b0 = s_rec[jB * 3 + 0], b1 = s_rec[jB * 3 + 1], b2 = s_rec[jB * 3 + 2];
+            for (int slot = 0; slot < count; slot += 2) {
+                const bool hasB = slot + 1 < count;
+                const float4* p = s_rec + slot * 3;
+                const float4 a0 = p[0], a1 = p[1], a2 = p[2];
+                const float4 b0 = p[3], b1 = p[4], b2 = p[5];
+                const int posA = (int)__float_as_uint(a2.z), posB = (int)__float_as_uint(b2.z);
                 // independent of (T, B)
                 const float dxA = a0.x - pxf[0], dyA = a0.y - pyf[0], dxB = b0.x - pxf[0], dyB = b0.y - pyf[0];
                 const float pA = ggs_falloff_log2(a0.z, a0.w, a1.x, dxA, dyA);
                 const float pB = ggs_falloff_log2(b0.z, b0.w, b1.x, dxB, dyB);
                 const float GrA = __builtin_amdgcn_exp2f(pA), GrB = __builtin_amdgcn_exp2f(pB);
                 const float arA = __builtin_fminf(GGS_ALPHA_MAX, a1.y * GrA), arB = __builtin_fminf(GGS_ALPHA_MAX, b1.y * GrB);
-                const bool validA = (first + jA < nc[0]) & (pA <= 0.f) & (arA >= GGS_ALPHA_MIN);
-                const bool validB = hasB & (first + jB < nc[0]) & (pB <= 0.f) & (arB >= GGS_ALPHA_MIN);
+                const bool validA = (posA < nc[0]) & (pA <= 0.f) & (arA >= GGS_ALPHA_MIN);
+                const bool validB = hasB & (posB < nc[0]) & (pB <= 0.f) & (arB >= GGS_ALPHA_MIN);
                 float sdotA = fmaf(a2.x, dC2[0], fmaf(a1.w, dC1[0], a1.z * dC0[0]));
                 float sdotB = fmaf(b2.x, dC2[0], fmaf(b1.w, dC1[0], b1.z * dC0[0]));
                 if (DA) { sdotA += fmaf(a2.y, dD[0], dA[0]); sdotB += fmaf(b2.y, dD[0], dA[0]); }
@@ -514,14 +529,26 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
                 // per-splat sums over this wave's pixels
                 const float tA = GA * dLA, tB = GB * dLB;
                 const float hxA = tA * dxA, hyA = tA * dyA, hxB = tB * dxB, hyB = tB * dyB;
-                reduce_add(wordA, hxA, hyA, hxA * dxA, hxA * dyA, hyA * dyA, tA, wA * dC0[0], wA * dC1[0], wA * dC2[0],
-                           DA ? wA * dD[0] : 0.f);
-                if (hasB)
-                    reduce_add(wordB, hxB, hyB, hxB * dxB, hxB * dyB, hyB * dyB, tB, wB * dC0[0], wB * dC1[0], wB * dC2[0],
-                               DA ? wB * dD[0] : 0.f);
+                const uint32_t gidA = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(a2.w));
+                if (hasB) {         // both reductions with their LDS round trips in flight together, one wait
+                    const uint32_t gidB = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(b2.w));
+                    const float xa[10] = {hxA, hyA, hxA * dxA, hxA * dyA, hyA * dyA, tA, wA * dC0[0], wA * dC1[0], wA * dC2[0],
+                                          DA ? wA * dD[0] : 0.f};
+                    const float xb[10] = {hxB, hyB, hxB * dxB, hxB * dyB, hyB * dyB, tB, wB * dC0[0], wB * dC1[0], wB * dC2[0],
+                                          DA ? wB * dD[0] : 0.f};
+                    float SA, SB;
+                    lds_transpose_reduce2<DA>(s_red, s_red2, lane, xa, xb, SA, SB);
+                    if (fld >= 0) {
+                        atomicAdd(reinterpret_cast<float*>(acc + gidA) + fld, SA);
+                        atomicAdd(reinterpret_cast<float*>(acc + gidB) + fld, SB);
+                    }
+                } else
+                    reduce_add(gidA, hxA, hyA, hxA * dxA, hxA * dyA, hyA * dyA, tA, wA * dC0[0], wA * dC1[0], wA * dC2[0],
+                               DA ? wA * dD[0] : 0.f);
             }
             continue;
         }
+        lds.put(cur, lane);
         // Per-tile waves keep the plain descending loop: they are throughput bound and the mask bookkeeping costs
         // what the skipped entries save.
         for (int j = n - 1; j >= 0; --j) {

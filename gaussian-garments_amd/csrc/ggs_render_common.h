@@ -95,6 +95,72 @@ __device__ __forceinline__ float lds_transpose_reduce(float* s_red, int lane, fl
     }
     return s;
 }
+// Two reductions at once (the two entries of a pair in the latency mapping): both sets of partials go out to two LDS planes, both
+// read-backs are in flight together and the wave waits ONCE -- a wave that has its SIMD to itself sits through the LDS round trip
+// of every reduction it does one after the other.  Same arithmetic per value as lds_transpose_reduce.
+template <bool DA>
+__device__ __forceinline__ void lds_transpose_reduce2(float* s_redA, float* s_redB, int lane, const float (&x)[10], const float (&y)[10],
+                                                      float& SA, float& SB) {
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f a, b, c, d, e, f, g, h;
+    const unsigned baseA = (unsigned)(uintptr_t)s_redA, baseB = (unsigned)(uintptr_t)s_redB;
+    const unsigned off = ((lane >> 3) * GGS_RED_STRIDE + (lane & 7) * 2) * 4;
+    const unsigned rdA = baseA + off, rdB = baseB + off;
+#define GGS_RED_WRITES                                                                                             \
+    "s_mov_b32 m0, %8\n\t"                                                                                         \
+    "s_nop 0\n\t"                                                                                                  \
+    "ds_write_addtid_b32 %0\n\t"                                                                                   \
+    "ds_write_addtid_b32 %1 offset:320\n\t"                                                                        \
+    "ds_write_addtid_b32 %2 offset:640\n\t"                                                                        \
+    "ds_write_addtid_b32 %3 offset:960\n\t"                                                                        \
+    "ds_write_addtid_b32 %4 offset:1280\n\t"                                                                       \
+    "ds_write_addtid_b32 %5 offset:1600\n\t"                                                                       \
+    "ds_write_addtid_b32 %6 offset:1920\n\t"                                                                       \
+    "ds_write_addtid_b32 %7 offset:2240"
+    asm volatile(GGS_RED_WRITES :: "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]), "s"(baseA)
+                 : "memory", "m0");
+    asm volatile(GGS_RED_WRITES :: "v"(y[0]), "v"(y[1]), "v"(y[2]), "v"(y[3]), "v"(y[4]), "v"(y[5]), "v"(y[6]), "v"(y[7]), "s"(baseB)
+                 : "memory", "m0");
+#undef GGS_RED_WRITES
+    asm volatile("ds_read_b64 %0, %8\n\t"
+                 "ds_read_b64 %1, %8 offset:64\n\t"
+                 "ds_read_b64 %2, %8 offset:128\n\t"
+                 "ds_read_b64 %3, %8 offset:192\n\t"
+                 "ds_read_b64 %4, %9\n\t"
+                 "ds_read_b64 %5, %9 offset:64\n\t"
+                 "ds_read_b64 %6, %9 offset:128\n\t"
+                 "ds_read_b64 %7, %9 offset:192"
+                 : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f), "=&v"(g), "=&v"(h) : "v"(rdA), "v"(rdB) : "memory");
+    // the ninth / tenth values of both: in-row DPP sums while the LDS reads are in flight
+    float t = DA ? swap32_add(x[8], x[9]) : x[8];
+    float u = DA ? swap32_add(y[8], y[9]) : y[8];
+    t += dpp_fetch<0xB1, 0xf>(t); u += dpp_fetch<0xB1, 0xf>(u);
+    t += dpp_fetch<0x4E, 0xf>(t); u += dpp_fetch<0x4E, 0xf>(u);
+    t += dpp_fetch<0x141, 0xf>(t); u += dpp_fetch<0x141, 0xf>(u);
+    t += dpp_fetch<0x140, 0xf>(t); u += dpp_fetch<0x140, 0xf>(u);
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h));
+    float s = ((a.x + a.y) + (b.x + b.y)) + ((c.x + c.y) + (d.x + d.y));
+    float r = ((e.x + e.y) + (f.x + f.y)) + ((g.x + g.y) + (h.x + h.y));
+    s += dpp_fetch<0xB1, 0xf>(s); r += dpp_fetch<0xB1, 0xf>(r);
+    s += dpp_fetch<0x4E, 0xf>(s); r += dpp_fetch<0x4E, 0xf>(r);
+    s += dpp_fetch<0x141, 0xf>(s); r += dpp_fetch<0x141, 0xf>(r);
+    if (DA) {
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_mov_b32_dpp %1, %0 quad_perm:[0,1,2,3] row_mask:0xa bank_mask:0x8\n\t"
+                     "v_mov_b32_dpp %3, %2 quad_perm:[0,1,2,3] row_mask:0xa bank_mask:0x8" : "+v"(t), "+v"(s), "+v"(u), "+v"(r));
+    } else {
+        asm volatile("s_nop 1\n\t"
+                     "v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "v_add_f32_dpp %2, %2, %2 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                     "s_nop 1\n\t"
+                     "v_add_f32_dpp %1, %0, %0 row_bcast:31 row_mask:0x8 bank_mask:0x8\n\t"
+                     "v_add_f32_dpp %3, %2, %2 row_bcast:31 row_mask:0x8 bank_mask:0x8" : "+v"(t), "+v"(s), "+v"(u), "+v"(r));
+    }
+    SA = s; SB = r;
+}
 // GradRec field the lane adds to after lds_transpose_reduce (-1: none)
 template <bool DA>
 __device__ __forceinline__ int lds_reduce_field(int lane) {
