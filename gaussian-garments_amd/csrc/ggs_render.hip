@@ -219,10 +219,17 @@ __device__ __forceinline__ PairAlpha test_pair(const PairRec& r, float pxf, floa
     return p;
 }
 
-// K4b body, latency mapping (one wave per (tile, quadrant), launches too small to fill the chip).  A wave that has
-// its SIMD almost to itself spends most of each splat waiting: LDS record read -> 9 dependent VALU ops of the alpha
-// test -> blend.  Two consecutive splats are therefore tested together (independent chains, both records read up
-// front) and blended one after the other; the arithmetic per pixel is the same as in render_fwd_body.
+// K4b body, latency mapping (one wave per (tile, quadrant), launches too small to fill the chip).  The kernel is as long as its
+// dozen longest walks (profiles/r05_wave_timeline.md), and those run on SIMDs they have to themselves.  What a lone wave pays
+// for is the NUMBER of instructions it issues -- ~6-9 cycles per VALU instruction whether or not it depends on the one before
+// (profiles/r02_valu_issue_rates.md), and the scalar ones are not free either -- not their latencies: hiding the LDS read and
+// the alpha test of the next pair behind the blend chain of the current one (software pipeline, round 5) bought 1.6 %, taking
+// instructions out of the walk bought the rest (90.4 -> 72 us for one 1080p view of config 2, profiles/r05_quad_forward.md):
+//   * the round's records are parked COMPACTED to the entries that reach the quadrant, with their list position in a spare
+//     field: a slot counter walks them (picking set bits out of a lane mask was ~20 scalar instructions per pair);
+//   * finished pixels are kept out by a scalar mask, exits are plain compare + branch pairs;
+//   * entries nobody in the quadrant took lose their bit through ONE vector atomic per round.
+// The arithmetic per pixel is the same as in render_fwd_body: bit-identical outputs.
 __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
     const bool overflow = a.header->overflow != 0;      // see render_fwd_body: overflowed forward = all tiles empty
     const uint32_t item = a.order[blockIdx.x / GGS_NQ];

@@ -11,7 +11,7 @@ cams = S.rig_cameras()
 with torch.no_grad():
     inp = (m.get_xyz, m.get_opacity, m.get_features, None, m.get_scaling, m.get_rotation, None)
 out = []
-for V in (1, 2, 3, 4, 6, 8):
+for V in (1, 2, 4, 6, 8, 10, 12, 16):
     ck = S.stack_cameras([cams[(7 * i) % 160] for i in range(V)], device=dev)
     dL = torch.randn(V, 3, H, W, device=dev)
     def run():

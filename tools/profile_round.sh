@@ -20,7 +20,7 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/gs -o g -- python 
 python $R/tools/rocpd_summary.py $(find $R/gpurun_out/gs -name "*.db" | head -1) --cycles 60 --anchor k_adam_multi > $R/gpurun_out/prof_${N}_graph_step_kernels.md 2>&1
 grep "graphed s2 step" $R/gpurun_out/gs.log >> $R/gpurun_out/prof_${N}_graph_step_kernels.md
 rm -rf $R/gpurun_out/gs
-( cd $R; echo; echo "Unprofiled (two runs each of \`python tools/profile_graph_step.py 256\` and \`... 256 --pipelined\`):"; for i in 1 2; do python tools/profile_graph_step.py 256 | tail -1; python tools/profile_graph_step.py 256 --pipelined | tail -1; done ) >> $R/gpurun_out/prof_${N}_graph_step_kernels.md 2>/dev/null
+( cd $R; echo; echo "Unprofiled (two runs each of \`python tools/profile_graph_step.py 256\`, \`... 256 --pipelined\` and \`... 256 --pipelined --silhouette [--plain-loss]\`):"; for i in 1 2; do python tools/profile_graph_step.py 256 | tail -1; python tools/profile_graph_step.py 256 --pipelined | tail -1; python tools/profile_graph_step.py 256 --pipelined --silhouette | tail -1; python tools/profile_graph_step.py 256 --pipelined --silhouette --plain-loss | tail -1; done ) >> $R/gpurun_out/prof_${N}_graph_step_kernels.md 2>/dev/null
 # serial / whole-forward pipelined / stage-granular pipelined step: which kernels were in flight together (tools/overlap_summary.py)
 ( cd $R; TAG=prof_${N} MODES="0 1 2" CHUNK=40 bash tools/dbg/job.sh pipetrace > /dev/null 2>&1 )
 # the 20-view rank step of an 8-GPU run, unprofiled, on one GPU + serial vs pipelined launch sets
