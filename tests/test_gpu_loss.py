@@ -250,7 +250,7 @@ def test_sparse_mask_form_through_the_python_wrapper_and_its_errors():
         img.grad = None
         a, b = fused_photometric_loss(img, gt, mask, 0.2, tile_count=tc, mask_tiles=tiles)
         (a + b).backward()
-        outs.append((float(a), float(b), img.grad.clone()))
+        outs.append((float(a.detach()), float(b.detach()), img.grad.clone()))
     assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[0][0]) and abs(outs[0][1] - outs[1][1]) <= 1e-6 * abs(outs[0][1])
     assert torch.equal(outs[0][2], outs[1][2])
     with pytest.raises(ValueError, match="mask_tiles needs"):
