@@ -465,9 +465,15 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
     // rounds of 64 list positions, walked from the back: round r covers [64 r, 64 r + 64)
     int r = (maxc - 1) >> 6;
     Rec3 nxt = gather_round(rec, ids, r * 64, L, lane);
+    // Latency mapping: id words two rounds ahead, records one round ahead, as in render_fwd_quadwave -- a lone wave otherwise sits
+    // out the id load of every round before it can even ask for the records (the tile waves have other waves to run meanwhile).
+    uint32_t w_ahead = 0;
+    if (NQ == 1 && r > 0) w_ahead = gather_ids(ids, (r - 1) * 64, L, lane);
     for (; r >= 0; --r) {
         const Rec3 cur = nxt;
-        if (r > 0) nxt = gather_round(rec, ids, (r - 1) * 64, L, lane);
+        if (NQ == 1) {
+            if (r > 0) { nxt = gather_recs(rec, w_ahead); if (r > 1) w_ahead = gather_ids(ids, (r - 2) * 64, L, lane); }
+        } else if (r > 0) nxt = gather_round(rec, ids, (r - 1) * 64, L, lane);
         const int first = r * 64;
         const int n = min(64, maxc - first);
         // Entries of the round the forward blended somewhere in this wave's pixels, as a lane mask (lane i holds entry i):
