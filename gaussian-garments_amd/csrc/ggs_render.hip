@@ -206,6 +206,12 @@ __device__ __forceinline__ PairRec load_pair(const float4* s_rec, int slot) {   
     r.a2x = a2.x; r.a2y = a2.y; r.posA = a2.z; r.b2x = b2.x; r.b2y = b2.y; r.posB = b2.z;
     return r;
 }
+// (hi:lo) <- (hi:lo) << 1 | (mask != 0): three scalar instructions, the compare's SCC shifted in through the carry
+__device__ __forceinline__ void push_taken(uint32_t& lo, uint32_t& hi, uint64_t mask) {
+    asm volatile("s_cmp_lg_u64 %2, 0\n\t"
+                 "s_addc_u32 %0, %0, %0\n\t"
+                 "s_addc_u32 %1, %1, %1" : "+s"(lo), "+s"(hi) : "s"(mask) : "scc");
+}
 // both alpha tests (independent of T and of each other)
 __device__ __forceinline__ PairAlpha test_pair(const PairRec& r, float pxf, float pyf) {
     PairAlpha p;
@@ -256,7 +262,7 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
     uint64_t dead = ~__builtin_amdgcn_ballot_w64(inside);          // pixels outside the image, later also the finished ones
     const uint32_t mine = 1u << (GGS_ID_BITS + q0);
 
-    __shared__ float4 s_rec[64 * 3];
+    __shared__ float4 s_rec[66 * 3];          // 64 slots + the two a walk reads ahead of its last pair (never used)
     RoundLds lds{s_rec};
     if (L > 0) {
         // id words two rounds ahead, records one round ahead (ggs_render_common.h): a lone wave would otherwise sit out the
@@ -296,12 +302,12 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
             // sets swap roles from step to step (the loop body is two steps), so nothing is copied at the back edge.
             // (Slots past `count` + 1 hold stale records: read, tested, never blended.)
             int slot = 0;
-            uint64_t taken = 0, bitA = 1;                       // bit s of `taken`: the entry in slot s was taken by some pixel
+            uint32_t tk_lo = 0, tk_hi = 0;      // shift register: one bit per visited entry, "some pixel took it", newest in bit 0
             // (two plain exits per step instead of one combined condition: on the scalar unit a compare + branch each, where the
             // combined form materialised both conditions as lane masks first)
 #define GGS_FWD_STEP(rc, pc, rn, pn)                                                                                           \
             {                                                                                                                  \
-                rn = load_pair(s_rec, (slot + 2) & 62);                                                                        \
+                rn = load_pair(s_rec, slot + 2);                                                                               \
                 asm volatile("" ::: "memory");   /* the six reads stay whole and up here (else they are split and sunk to their uses) */ \
                 /* ---- blend A, then B (in list order) */                                                                    \
                 const uint64_t okA = pc.okA & ~dead;                                                                           \
@@ -331,8 +337,7 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
                 /* ---- the alpha tests of the next pair (independent of everything above) */                                  \
                 pn = test_pair(rn, pxf, pyf);                                                                                  \
                 /* which of the two entries anybody in this quadrant took (see below the walk) */                              \
-                taken |= (okA != 0 ? bitA : 0ull) | (okB != 0 ? bitA << 1 : 0ull);                                             \
-                bitA <<= 2;                                                                                                    \
+                push_taken(tk_lo, tk_hi, okA); push_taken(tk_lo, tk_hi, okB);                                                  \
                 slot += 2;                                                                                                     \
                 if (slot >= count) break;                                                                                      \
                 if (dead == ~0ull) goto round_done;                                                                            \
@@ -352,11 +357,12 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
             // fifth of the walk's instructions.  Entries behind the point where the last pixel finished keep their bits: the
             // backward stops at the last contributor.
             {
+                // the shift register holds one bit per entry of every pair walked (the filler behind an odd count included), the
+                // newest in bit 0: the entry of slot s sits at bit slot - 1 - s
                 const int visited = min(slot, count);
-                const uint64_t seen = visited >= 64 ? ~0ull : (1ull << visited) - 1ull;
-                const uint64_t drop = seen & ~taken;                                     // by slot
+                const uint64_t tk = ((uint64_t)tk_hi << 32) | tk_lo;
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
-                if (((todo >> lane) & 1ull) && ((drop >> rank) & 1ull)) atomicAnd(&ids[first + lane], ~mine);
+                if (((todo >> lane) & 1ull) && rank < visited && !((tk >> (slot - 1 - rank)) & 1ull)) atomicAnd(&ids[first + lane], ~mine);
             }
             if (dead == ~0ull) break;
         }
