@@ -421,6 +421,10 @@ def model_golden():
             rec["get_xyz"], rec["get_scaling"] = m.get_xyz.numpy().copy(), m.get_scaling.numpy().copy()
             rec["get_opacity"], rec["get_features"] = m.get_opacity.numpy().copy(), m.get_features.numpy().copy()
             rec["face_center"], rec["face_scaling"] = m.face_center.numpy().copy(), m.face_scaling.numpy().copy()
+            # the face frame get_rotation composes with (scene/mesh_gaussian_model.py:117-122 multiplies its QUATERNION through
+            # roma; the same frame as a matrix is what get_xyz uses, :124-128): R(get_rotation) = face_orien_mat[binding] R(normalize(_rotation))
+            rec["face_orien_mat"] = m.face_orien_mat.numpy().copy()
+            rec["getters_binding"], rec["getters_rotation_raw"] = m.binding.numpy().copy(), m._rotation.detach().numpy().copy()
             # get_covariance(scaling_modifier): the LOCAL rotation with the mesh-bound scaling (scene/gaussian_model.py:118-119)
             rec["get_covariance_1p5"] = m.get_covariance(1.5).numpy().copy()
             # update_learning_rate (scene/gaussian_model.py:171-177): the "xyz" group only

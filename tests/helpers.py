@@ -15,6 +15,16 @@ def rel_l1(a, b) -> float:
     return float((a - b).abs().sum() / (b.abs().sum() + 1e-30))
 
 
+def quat_wxyz_to_rotmat(q):
+    """Rotation matrix of (w, x, y, z) quaternions, in float64 (q and -q give the same matrix: sign-free comparisons)."""
+    q = torch.as_tensor(q).detach().cpu().double()
+    q = q / q.norm(dim=-1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    return torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                        2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                        2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1).reshape(*q.shape[:-1], 3, 3)
+
+
 def cam_kwargs(cam, bg):
     return dict(viewmatrix=cam.world_view_transform, projmatrix=cam.full_proj_transform, campos=cam.camera_center,
                 bg=torch.as_tensor(bg, dtype=torch.float32), W=cam.image_width, H=cam.image_height,

@@ -214,6 +214,31 @@ def test_training_setup_matches_reference(is_ff):
     assert [*m.xyz_gradient_accum.shape, *m.denom.shape] == list(t[f"{tag}_stats_shapes"])
 
 
+def test_quaternion_product_is_pinned_to_the_reference_face_frame():
+    """get_rotation (scene/mesh_gaussian_model.py:117-122) composes the face quaternion with the local one through roma, which
+    the authoring image lacks -- but the face FRAME is pinned (face_orientation.npz: the reference's compute_face_orientation)
+    and the reference's own get_xyz (:124-128) fixes the composition order as face_orien_mat[binding] @ local.  So, sign-free:
+    R(get_rotation[i]) == face_orien_mat[binding[i]] @ R(normalize(_rotation[i])).  Host oracle here (rotmat -> quaternion in
+    all four branches, xyzw -> wxyz, Hamilton product, normalisation); the HIP binding kernel in tests/test_gpu_mesh_bind.py."""
+    from helpers import quat_wxyz_to_rotmat
+    d = _load("face_orientation.npz")
+    v, f, R_ref = torch.tensor(d["verts"]), torch.tensor(d["faces"]), torch.tensor(d["orientation"]).double()
+    g = torch.Generator().manual_seed(17)
+    P = 8 * f.shape[0]
+    binding = torch.randint(0, f.shape[0], (P,), generator=g)
+    raw = torch.randn(P, 4, generator=g) * torch.rand(P, 1, generator=g) * 3          # un-normalised, as the parameter is
+    _, _, rot = HO.mesh_bind(v, f, binding, torch.zeros(P, 3), torch.zeros(P, 3), raw)
+    assert float((rot.norm(dim=1) - 1).abs().max()) < 1e-6
+    want = R_ref[binding] @ quat_wxyz_to_rotmat(raw)
+    assert float((quat_wxyz_to_rotmat(rot) - want).abs().max()) <= 1e-6
+    # every branch of the rotmat -> quaternion construction occurs in the fixture
+    dec = torch.cat([R_ref.diagonal(dim1=1, dim2=2), R_ref.diagonal(dim1=1, dim2=2).sum(1, keepdim=True)], 1)
+    assert set(dec.argmax(1).tolist()) == {0, 1, 2, 3}
+    # ... and the composition order matters on this fixture (the other order is off by O(1))
+    swapped = quat_wxyz_to_rotmat(raw) @ R_ref[binding]
+    assert float((quat_wxyz_to_rotmat(rot) - swapped).abs().max()) > 0.1
+
+
 _RENDER_SCENARIOS = {
     "default": (dict(), dict(debug=False, compute_cov3D_python=False, convert_SHs_python=False), False, False),
     "s3": (dict(vis_mask=True), dict(debug=False, compute_cov3D_python=False, convert_SHs_python=False), True, True),

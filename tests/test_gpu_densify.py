@@ -262,11 +262,18 @@ def test_getters_schedule_and_reset_opacity_match_the_reference():
     """The mesh-bound getters (get_xyz / get_scaling through the fused HIP binding kernel; scene/mesh_gaussian_model.py:105-128),
     get_opacity / get_features / get_covariance, update_learning_rate (scene/gaussian_model.py:171-177) and reset_opacity
     (:212-215 + replace_tensor_to_optimizer :261-274) of the model mirror against what the REFERENCE's own model class returned
-    on the same state (tests/golden/densify.npz; get_rotation is not in the golden: it needs roma, which the authoring image
-    lacks -- the quaternion path is covered by tests/test_gpu_mesh_bind.py against the host oracle)."""
+    on the same state (tests/golden/densify.npz).  get_rotation needs roma, which the authoring image lacks: its expected value
+    is composed from what the reference DID record on that state -- face_orien_mat, binding, _rotation -- in the order the
+    reference's get_xyz fixes (:117-128): R(get_rotation) = face_orien_mat[binding] R(normalize(_rotation)), compared sign-free."""
+    from helpers import quat_wxyz_to_rotmat
     d = np.load(G)
     m = golden_model(d)
     with torch.no_grad():
+        assert close(m.face_orien_mat, d["face_orien_mat"], 2e-6, 2e-6)
+        assert np.array_equal(m.binding.cpu().numpy(), d["getters_binding"]) and close(m._rotation, d["getters_rotation_raw"], 1e-6, 1e-7)
+        want = torch.tensor(d["face_orien_mat"]).double()[torch.tensor(d["getters_binding"])] @ quat_wxyz_to_rotmat(d["getters_rotation_raw"])
+        assert float((quat_wxyz_to_rotmat(m.get_rotation) - want).abs().max()) <= 2e-6
+        assert float((m.get_rotation.norm(dim=1) - 1).abs().max()) < 1e-6
         assert close(m.get_xyz, d["get_xyz"], 2e-6, 2e-7) and close(m.get_scaling, d["get_scaling"], 2e-6, 1e-9)
         assert close(m.face_center, d["face_center"], 2e-6, 2e-7) and close(m.face_scaling, d["face_scaling"], 2e-6, 1e-9)
         assert close(m.get_opacity, d["get_opacity"], 2e-6, 1e-8) and close(m.get_features, d["get_features"], 1e-5, 1e-7)
