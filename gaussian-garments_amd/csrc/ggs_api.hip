@@ -412,7 +412,7 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
     }  // PHASE_BIN
     if (phases & PHASE_COMPOSITE) {
         RenderArgs a;
-        a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.header = header;
+        a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.header = header; a.poison = p->debug;
         a.n_items = n_items; a.order = order; a.tile_count = tile_count; a.tile_offset = tile_offset; a.view_base = view_base; a.ids = ids;
         a.rec = (const SplatRec*)geom; a.bg = bg; a.out_color = out_color; a.out_depth = out_depth;
         a.out_alpha = out_alpha; a.final_T = final_T; a.n_contrib = n_contrib;
@@ -445,6 +445,9 @@ int ggs_forward_render(GGS_FWD_PARAMS) { return forward_impl(PHASE_RENDER, GGS_F
 int ggs_forward_stages(int stages, GGS_FWD_PARAMS) {
     if (stages <= 0 || (stages & ~(PHASE_COUNT | PHASE_RENDER)))
         return fail(GGS_ERR_ARG, "ggs_forward_stages: stages=%d is not a combination of GGS_STAGE_COUNT | _BIN | _COMPOSITE", stages);
+    // a contiguous run only: COUNT | COMPOSITE would re-clear the counters and then composite against the lists of an earlier call
+    if (stages == (GGS_STAGE_COUNT | GGS_STAGE_COMPOSITE))
+        return fail(GGS_ERR_ARG, "ggs_forward_stages: GGS_STAGE_COUNT | GGS_STAGE_COMPOSITE skips GGS_STAGE_BIN (stages must be a contiguous run)");
     return forward_impl(stages, GGS_FWD_ARGS);
 }
 int ggs_forward_spec(GGS_FWD_PARAMS, void* host_header, void* header_event) {
@@ -488,7 +491,7 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
         return fail(GGS_ERR_HIP, "ggs_backward: clearing the gradient records failed: %s", hipGetErrorString(hipGetLastError()));
     {
         RenderBwdArgs a;
-        a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T;
+        a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.poison = p->debug;
         a.n_items = V * d.T; a.order = (const uint32_t*)(b + L.order);
         a.bucket_count = (const uint32_t*)(b + L.header + GGS_BUCKET_COUNT_OFF);
         a.tile_count = (const uint32_t*)(b + L.tile_count);

@@ -60,6 +60,7 @@ struct SortArgs {
 
 struct RenderArgs {
     int P, W, H, gx, gy, T, n_items;
+    int poison;               // GgsParams.debug: the per-quadrant walks fill their LDS record slice with NaNs before every round
     const uint32_t* order;
     const GgsBinHeader* header;
     const uint32_t* tile_count;
@@ -77,6 +78,7 @@ struct RenderArgs {
 
 struct RenderBwdArgs {
     int P, W, H, gx, gy, T, n_items;
+    int poison;               // as RenderArgs.poison
     const uint32_t* order;
     const uint32_t* bucket_count;     // [GGS_NBUCKET] list-length class histogram (position of the non-empty items)
     const uint32_t* tile_count;

@@ -95,22 +95,15 @@ __device__ __forceinline__ float block_sum(float v, float* s_red) {
 // the loads of the next row -> filter.  Loads are branch-free (clamped addresses, padding applied at park time) and the
 // stores are issued BEFORE the loads that the next step waits for: vmcnt retires in order, so a store issued after
 // them would put its whole write latency on the critical path of every step.
-// Build switches of pass A (A/B libraries: tools/dbg/build_variant.sh with ALL_EXTRA="-DGGS_LOSS_WAVES=4 ..."): waves per SIMD
-// the register allocation aims at, and how many input rows ahead of the one being filtered the loads run.  The pass is bound
+// Shape of pass A: GGS_LOSS_WAVES waves per SIMD is what the register allocation aims at, and the loads run TWO input rows ahead
+// of the one being filtered (the alternatives -- one row ahead, 2 / 4 waves, the second group of LDS reads fenced behind the
+// first -- were A/B builds: tools/dbg/variants/r06_loss_ahead_and_split_reads_switches.patch).  The pass is bound
 // by the LATENCY of a row step (load -> LDS -> 44 reads -> filter -> SSIM chain), not by its instruction count: going from
 // five maps / 215 VALU per row to four / 167 changed nothing at 4 waves per SIMD, where 15-28 registers spill into the
 // chain (scratch round trips); 3 waves without spills and loads two rows ahead measure, us per 1080p view (tools/dbg/time_loss.py,
 // one view | 16 views):  round 3 kernel 69 | 59;  4 waves, 1 row ahead 65 | 57;  3 waves, 1 ahead 61 | 57;  4 waves, 2 ahead 76 | 71;
 // 2 waves, 2 ahead 69 | 56;  **3 waves, 2 ahead 54 | 50.5** (region-of-interest form 55 | 36).
-#ifndef GGS_LOSS_WAVES
 #define GGS_LOSS_WAVES 3
-#endif
-#ifndef GGS_LOSS_AHEAD
-#define GGS_LOSS_AHEAD 2
-#endif
-#ifndef GGS_LOSS_SPLIT_READS                         // 1: at most 22 LDS values in flight (what 128 VGPRs hold without spilling more)
-#define GGS_LOSS_SPLIT_READS (GGS_LOSS_WAVES >= 4)
-#endif
 // Pass A comes in two workgroup shapes.  NCH = 3: a workgroup holds the three colour channels of its four bands (12 waves = one
 // CU's worth at 3 waves per SIMD): 240 workgroups per view instead of 720 end in the two same-address atomics of the sums -- those
 // retire one every ~10 ns, and when all workgroups of a view finish together that tail is 7.5 of the kernel's 48 us (one view:
@@ -193,9 +186,7 @@ struct StatsCtx {
     float l1, ssum;
     float s0;                 // sparse-mask form: the SSIM value of an all-zero window (ssum then collects S - s0)
     StatsRow nxt;
-#if GGS_LOSS_AHEAD == 2
     StatsRow nxt2;            // the row after `nxt`, in flight
-#endif
     float o0, o1, o2;         // outputs of the previous step, written at the start of this one
     bool pend;
 };
@@ -234,12 +225,8 @@ __device__ __forceinline__ void stats_step(StatsCtx& c, RowRing<4>& ring, int i)
         const uint32_t p = ((uint32_t)(c.oy + i - 1 - 2 * LH) * (uint32_t)c.W + (uint32_t)x) * 4u;
         st_off(c.dm, p, c.o0); st_off(c.dm1, p, c.o1); st_off(c.dm2, p, c.o2);
     }
-#if GGS_LOSS_AHEAD == 2
     c.nxt = c.nxt2;
     c.nxt2 = stats_load_row<MASK>(c.img, c.gt, c.mask, c.oy - LH + i + 2, c.H, c.W, c.ox, lane);
-#else
-    c.nxt = stats_load_row<MASK>(c.img, c.gt, c.mask, c.oy - LH + i + 1, c.H, c.W, c.ox, lane);
-#endif
     // two maps at a time (22 values in flight, not 44: the ring of vertical partial sums already holds 44 registers)
     float h[4] = {0.f, 0.f, 0.f, 0.f};
     {
@@ -251,9 +238,6 @@ __device__ __forceinline__ void stats_step(StatsCtx& c, RowRing<4>& ring, int i)
         // L1 over the strip's own pixels (the row is an own row when LH <= i < LH + LS_HB)
         if (i >= LH && i < LH + HB && c.oy + i - LH < c.H && x < c.W) c.l1 += fabsf(xs[LH] - ys[LH]);
     }
-#if GGS_LOSS_SPLIT_READS
-    asm volatile("" ::: "memory");                   // keeps the second group's LDS reads behind the first group's use
-#endif
     {
         float sq[11], pr[11];
 #pragma unroll
@@ -336,9 +320,7 @@ __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float 
 #pragma unroll
             for (int m = 0; m < 4; ++m) ring.v[j][m] = 0.f;
         c.nxt = stats_load_row<MASK>(c.img, c.gt, c.mask, c.oy - LH, c.H, c.W, c.ox, lane);
-#if GGS_LOSS_AHEAD == 2
         c.nxt2 = stats_load_row<MASK>(c.img, c.gt, c.mask, c.oy - LH + 1, c.H, c.W, c.ox, lane);
-#endif
         static_assert((HB + 2 * LH) % 11 == 0, "the row loop is unrolled by 11");
         for (int i0 = 0; i0 < HB + 2 * LH; i0 += 11) unroll11<0, StatsStep<MASK, HB, SPARSE>>(c, ring, i0);
         if (c.pend && c.dm) {                                            // the last output row
@@ -364,9 +346,7 @@ __device__ __forceinline__ void loss_stats_stream_body(const LossArgs& a, float 
 // Pass A: grid (ceil(W/64), ceil(ceil(H/HB)/4), V * 3 / NCH), block 256 NCH = 4 NCH independent waves.
 // (Masked and unmasked forms are separate kernels: as two branches of one kernel the register allocation of the shared
 // prologue pushed the masked body over its register budget.)
-#ifndef LS_HB_SPARSE                      // 12, 23 or 34 (LS_HB_SPARSE + 10 must be a multiple of 11)
-#define LS_HB_SPARSE 12
-#endif
+#define LS_HB_SPARSE 12                   // 12, 23 or 34 (LS_HB_SPARSE + 10 must be a multiple of 11)
 #define GGS_LOSS_STATS_KERNEL(NAME, MASK, NCH, HB, SPARSE)                                                                  \
     __global__ __launch_bounds__(256 * NCH) __attribute__((amdgpu_waves_per_eu(GGS_LOSS_WAVES, GGS_LOSS_WAVES))) void NAME(LossArgs a) { \
         __shared__ float s_x[LS_WAVES * NCH][4][2][LS_IN];                                                                  \

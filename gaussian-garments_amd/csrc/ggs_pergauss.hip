@@ -10,11 +10,6 @@
 // that radii / tile rectangles / sort keys are bit-identical to oracle/splat_oracle.c.
 #include "ggs_kernels.h"
 
-// 1: the per-Gaussian backward stages the SH coefficients of its 256 Gaussians in LDS once (A/B switch, see preprocess_bwd_body)
-#ifndef GGS_PREBWD_SH_LDS
-#define GGS_PREBWD_SH_LDS 1
-#endif
-
 namespace {
 
 template <int DEG>
@@ -380,10 +375,10 @@ __device__ __forceinline__ float* ggs_grad_slot(const PreBwdArgs& a, int c, int 
 template <int DEG>
 __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a) {
     constexpr int NK3 = 3 * (DEG + 1) * (DEG + 1);
-#if GGS_PREBWD_SH_LDS
     // SH coefficients of the workgroup's 256 Gaussians, staged ONCE: the view loop below re-read them from global memory for every
     // view -- a lane's 12 NK bytes as 16-byte loads whose 64 lanes touch 64 different cache lines each (19 MB per view through
-    // the L2 at K = 16).  Row stride NK3 | 1 floats: lane l reads bank (stride l + j) mod 32, conflict-free.
+    // the L2 at K = 16; K = 16: 7.0 -> 5.3 us per view; the global-read form: tools/dbg/variants/r06_prebwd_sh_global_reads.patch).
+    // Row stride NK3 | 1 floats: lane l reads bank (stride l + j) mod 32, conflict-free.
     constexpr int SH_LD = NK3 | 1;
     __shared__ float s_sh[DEG > 0 ? 256 * SH_LD : 1];
     const bool stage_sh = DEG > 0 && !a.colors && a.dL_dsh;
@@ -396,7 +391,6 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a) {
         }
         __syncthreads();
     }
-#endif
     const int g = blockIdx.x * 256 + threadIdx.x;
     if (g >= a.P) return;
     const float m[3] = {a.means3D[3 * (size_t)g], a.means3D[3 * (size_t)g + 1], a.means3D[3 * (size_t)g + 2]};
@@ -508,11 +502,7 @@ __device__ __forceinline__ void preprocess_bwd_body(const PreBwdArgs& a) {
             float d[3] = {m[0] - campos[0], m[1] - campos[1], m[2] - campos[2]};
             const float len = sqrtf(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
             d[0] = d[0] / len; d[1] = d[1] / len; d[2] = d[2] / len;
-#if GGS_PREBWD_SH_LDS
             const float* sh = DEG > 0 ? s_sh + threadIdx.x * SH_LD : a.shs + (size_t)g * a.K * 3;   // degree 0: sh is never read
-#else
-            const float* sh = a.shs + (size_t)g * a.K * 3;
-#endif
             sh_backward<DEG>(sh, dshr, d, len, gsh, dmean);
         }
     }

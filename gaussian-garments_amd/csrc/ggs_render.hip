@@ -191,6 +191,19 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
 }
 
 
+// GgsParams.debug (the reference's pipe.debug) also arms a self-check of the latency mapping: the walks below park the records of
+// a round COMPACTED into the low slots of their LDS slice and deliberately read one pair past the last one (read, tested, never
+// blended: slots past count + 1 hold whatever an earlier round or an earlier kernel left there).  With the slice filled with NaNs
+// in front of every round, anything stale that reaches an output shows up as a NaN -- tests/test_gpu_fullsize.py compares such a
+// run bit for bit with the tile-wave mapping.  What keeps stale slots out: the forward blends an entry only where okA /
+// okB is set, and a NaN exponent fails `p <= 0`; the filler behind an odd count has opacity 0 (0 x exp2(finite) = 0, where
+// fminf(0.99, NaN) would be 0.99); the backward multiplies by alpha = G = 0 selected through `valid`, not by a product with 0.
+__device__ __forceinline__ void poison_slots(float4* s_rec, int n, int lane) {
+    const float q = __builtin_nanf("");
+    for (int i = lane; i < n; i += 64) s_rec[i] = make_float4(q, q, q, q);
+    __builtin_amdgcn_wave_barrier();
+}
+
 // The walk of the latency mapping takes the entries that reach its quadrant two at a time.  The records of a round are parked
 // in the LDS COMPACTED to those entries (slot = rank among them), each with its 1-based list position in the spare field c.z: the
 // walk is then a counter over the slots -- on a wave that has its SIMD to itself every instruction costs issue time, the scalar
@@ -263,7 +276,6 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
     const uint32_t mine = 1u << (GGS_ID_BITS + q0);
 
     __shared__ float4 s_rec[66 * 3];          // 64 slots + the two a walk reads ahead of its last pair (never used)
-    RoundLds lds{s_rec};
     if (L > 0) {
         // id words two rounds ahead, records one round ahead (ggs_render_common.h): a lone wave would otherwise sit out the
         // id load of every round before it can ask for the records (one view: 101 -> 94 us; the tile-wave mapping has other
@@ -282,6 +294,7 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
             {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
                 __builtin_amdgcn_wave_barrier();
+                if (a.poison) poison_slots(s_rec, 66 * 3, lane);       // debug mode: see poison_slots
                 if ((todo >> lane) & 1ull) {
                     const float4 c = make_float4(cur.c.x, cur.c.y, __uint_as_float((uint32_t)(first + lane + 1)), 0.f);
                     s_rec[rank * 3 + 0] = cur.a; s_rec[rank * 3 + 1] = cur.b; s_rec[rank * 3 + 2] = c;
@@ -500,6 +513,7 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
             {
                 const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(todo >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)todo, 0u));
                 __builtin_amdgcn_wave_barrier();
+                if (a.poison) poison_slots(s_rec, 64 * 3, lane);       // debug mode: see poison_slots
                 if ((todo >> lane) & 1ull) {
                     const int sl = count - 1 - rank;
                     const float4 c = make_float4(cur.c.x, cur.c.y, __uint_as_float((uint32_t)(first + lane)),

@@ -19,17 +19,10 @@ __device__ __forceinline__ float swap32_add(float x, float y) {
 }
 // log2 of the Gaussian falloff at offset (dx, dy) from the splat's centre, conic pre-scaled by the preprocess pass
 // (cxx, cxy, cyy) = (-log2e / 2, -log2e, -log2e / 2) x conic.  ONE definition: the forward, the backward and ggs_count_blends
-// must agree to the bit on which pixels pass the alpha test.  GGS_FALLOFF_OPS = 5: dx (cxx dx + cxy dy) + (cyy dy) dy as
-// three products and two fused multiply-adds; 6: the form of rounds 1-3 (four products, two fma).
-#ifndef GGS_FALLOFF_OPS
-#define GGS_FALLOFF_OPS 5
-#endif
+// must agree to the bit on which pixels pass the alpha test.  dx (cxx dx + cxy dy) + (cyy dy) dy as three products and two fused
+// multiply-adds (the six-operation form of rounds 1-3: tools/dbg/variants/r06_falloff_six_ops.patch; backward +0.6 us per view).
 __device__ __forceinline__ float ggs_falloff_log2(float cxx, float cxy, float cyy, float dx, float dy) {
-#if GGS_FALLOFF_OPS == 5
     return fmaf(dx, fmaf(cxx, dx, cxy * dy), (cyy * dy) * dy);
-#else
-    return fmaf(cxx * dx, dx, fmaf(cyy * dy, dy, (cxy * dx) * dy));
-#endif
 }
 
 // ---- wave reduction of the 9 (10) per-splat gradient sums through an LDS transpose ------------------------

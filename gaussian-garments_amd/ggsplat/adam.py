@@ -39,7 +39,11 @@ class GraphAdam:
         L = lib()
         self._state_bytes = int(L.ggs_adam_state_bytes())
         self._lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
-        self._lr_host = torch.zeros(len(self.param_groups), dtype=torch.float32).pin_memory()
+        # pinned staging rows of push_lr, used round robin, each with the event of its last upload: with iterations in flight
+        # (PipelinedRegistrationStep has no per-iteration host sync) the next push must not rewrite a row whose copy has not run
+        self._lr_host = torch.zeros(4, len(self.param_groups), dtype=torch.float32).pin_memory()
+        self._lr_ev = [None] * 4
+        self._lr_slot = 0
         self.state: Dict[torch.Tensor, Dict[str, torch.Tensor]] = {}
         for g in self.param_groups:
             for p in g["params"]:
@@ -52,10 +56,18 @@ class GraphAdam:
 
     # ---- learning rates ---------------------------------------------------------------------------------
     def push_lr(self) -> None:
-        """Upload param_groups[i]["lr"] to the device (call after changing a learning rate, outside a capture)."""
+        """Upload param_groups[i]["lr"] to the device (call after changing a learning rate, outside a capture).  Asynchronous:
+        the values take effect for the work queued AFTER this call on the current stream."""
+        k = self._lr_slot
+        self._lr_slot = (k + 1) % len(self._lr_ev)
+        if self._lr_ev[k] is not None:
+            self._lr_ev[k].synchronize()          # the copy that last read this row (four pushes ago) has run
+        row = self._lr_host[k]
         for i, g in enumerate(self.param_groups):
-            self._lr_host[i] = float(g["lr"])
-        self._lr_dev.copy_(self._lr_host, non_blocking=True)
+            row[i] = float(g["lr"])
+        self._lr_dev.copy_(row, non_blocking=True)
+        ev = self._lr_ev[k] = self._lr_ev[k] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.device))
 
     @property
     def step_count(self) -> int:

@@ -55,6 +55,14 @@ def fwd_bwd_views(inputs: Dict[str, torch.Tensor], cams: Dict[str, torch.Tensor]
             return r
         pipeline = 0                        # no learnt capacity yet (first call of this shape): the serial form learns it
     pipeline = bool(pipeline) and V > chunk and dev.type == "cuda"
+    return _fwd_bwd_views_serial(inputs, cams, bg=bg, W=W, H=H, sh_degree=sh_degree, dL_dcolor_fn=dL_dcolor_fn, chunk=chunk,
+                                 keep_images=keep_images, want_means2D=want_means2D, pipeline=pipeline)
+
+
+def _fwd_bwd_views_serial(inputs, cams, *, bg, W, H, sh_degree, dL_dcolor_fn, chunk, keep_images, want_means2D, pipeline):
+    """pipeline False: launch sets one after the other; True: the backward of set i on the second stream (fwd_bwd_views)."""
+    V = cams["view"].shape[0]
+    dev = inputs["means3D"].device
     grads: Optional[Dict[str, torch.Tensor]] = None
     n_total = 0
     images: List[torch.Tensor] = []
@@ -70,35 +78,37 @@ def fwd_bwd_views(inputs: Dict[str, torch.Tensor], cams: Dict[str, torch.Tensor]
         grads = R.new_grads(P, shs.shape[1] if shs is not None else 0, shs is not None, inputs.get("cov3D_precomp") is not None, dev)
         side.wait_stream(main)
     first = True
-    for v0 in range(0, V, chunk):
-        v1 = min(V, v0 + chunk)
-        color, radii, depth, alpha, st = R.forward_views(
-            inputs["means3D"], inputs["opacities"], inputs.get("shs"), inputs.get("colors_precomp"),
-            inputs.get("scales"), inputs.get("rotations"), inputs.get("cov3D_precomp"),
-            view=cams["view"][v0:v1], proj=cams["proj"][v0:v1], campos=cams["campos"][v0:v1],
-            tanfov=cams["tanfov"][v0:v1], bg=bg, W=W, H=H, sh_degree=sh_degree)
-        n_total += st.num_rendered
-        dL = dL_dcolor_fn(v0, v1, color)
-        if want_means2D and grads is not None:
-            grads["means2D"] = m2d[v0:v1]
-        if pipeline:
-            ev = torch.cuda.Event()
-            ev.record(main)
-            with torch.cuda.stream(side):
-                side.wait_event(ev)
-                R.backward_views(st, dL, want_means2D=want_means2D, out=grads, accumulate=not first)
-            keep.append((st, color, radii, depth, alpha, dL))
-        elif grads is None:
-            grads = R.backward_views(st, dL, want_means2D=want_means2D, out={"means2D": m2d[v0:v1]} if want_means2D else None)
-        else:
-            R.backward_views(st, dL, want_means2D=want_means2D, out=grads, accumulate=True)
-        first = False
-        if keep_images:
-            images.append(color)
-        del st
-    if pipeline:
-        main.wait_stream(side)
-        keep.clear()
+    try:
+        for v0 in range(0, V, chunk):
+            v1 = min(V, v0 + chunk)
+            color, radii, depth, alpha, st = R.forward_views(
+                inputs["means3D"], inputs["opacities"], inputs.get("shs"), inputs.get("colors_precomp"),
+                inputs.get("scales"), inputs.get("rotations"), inputs.get("cov3D_precomp"),
+                view=cams["view"][v0:v1], proj=cams["proj"][v0:v1], campos=cams["campos"][v0:v1],
+                tanfov=cams["tanfov"][v0:v1], bg=bg, W=W, H=H, sh_degree=sh_degree)
+            n_total += st.num_rendered
+            dL = dL_dcolor_fn(v0, v1, color)
+            if want_means2D and grads is not None:
+                grads["means2D"] = m2d[v0:v1]
+            if pipeline:
+                ev = torch.cuda.Event()
+                ev.record(main)
+                with torch.cuda.stream(side):
+                    side.wait_event(ev)
+                    R.backward_views(st, dL, want_means2D=want_means2D, out=grads, accumulate=not first)
+                keep.append((st, color, radii, depth, alpha, dL))
+            elif grads is None:
+                grads = R.backward_views(st, dL, want_means2D=want_means2D, out={"means2D": m2d[v0:v1]} if want_means2D else None)
+            else:
+                R.backward_views(st, dL, want_means2D=want_means2D, out=grads, accumulate=True)
+            first = False
+            if keep_images:
+                images.append(color)
+            del st
+    finally:
+        if pipeline:                        # also when the callback or a launch raised: the second stream is joined BEFORE the
+            main.wait_stream(side)          # tensors it reads are released
+            keep.clear()
     grads = grads or {}
     grads["num_rendered"] = n_total
     if want_means2D:
@@ -115,7 +125,9 @@ def _fwd_bwd_views_staged(inputs, cams, *, bg, W, H, sh_degree, dL_dcolor_fn, ch
     overlap.md).  Here everything with wide workgroups of set i + 1 -- count and bin -- is queued IN FRONT of the backward of set
     i on the caller's stream, and only the compositing of set i + 1 (one-wave workgroups, like the backward's) runs beside it
     on the second stream.  Needs the binning capacity of this shape (learnt by an earlier serial call): returns None if there
-    is none.  No host sync inside; num_rendered is read from the device headers at the end."""
+    is none.  No host sync inside; num_rendered is read from the device headers at the end.  If a set overflowed its capacity
+    (seen only then) the call returns None and fwd_bwd_views repeats the step serially: dL_dcolor_fn is then invoked a SECOND
+    time for every set -- a callback that accumulates (loss sums, logs) must tolerate that or use pipeline <= 1."""
     V = cams["view"].shape[0]
     dev = inputs["means3D"].device
     bounds = [(v0, min(V, v0 + chunk)) for v0 in range(0, V, chunk)]
@@ -128,44 +140,51 @@ def _fwd_bwd_views_staged(inputs, cams, *, bg, W, H, sh_degree, dL_dcolor_fn, ch
                                proj=cams["proj"][v0:v1], campos=cams["campos"][v0:v1], tanfov=cams["tanfov"][v0:v1], bg=bg,
                                W=W, H=H, sh_degree=sh_degree)
     try:
-        fwds = [staged(*b) for b in bounds]
+        cur = staged(*bounds[0])            # (at most two sets are alive at a time: the one being differentiated and the next)
     except R._lib.GgsError:
         return None
     main, side = torch.cuda.current_stream(dev), _side_stream(dev)
     grads = R.new_grads(P, shs.shape[1] if shs is not None else 0, shs is not None, inputs.get("cov3D_precomp") is not None, dev)
     m2d = torch.empty(V, P, 3, device=dev, dtype=torch.float32) if want_means2D else None
+    hdrs = torch.empty(len(bounds), 2, dtype=torch.int64, device=dev)      # {num_rendered, overflow} of every set
     SF = R.StagedForward
     side.wait_stream(main)
-    fwds[0].run(SF.COUNT | SF.BIN | SF.COMPOSITE)
-    composited = None                       # event: compositing of the set whose backward comes next (None: it ran on `main`)
-    for i, (v0, v1) in enumerate(bounds):
-        nxt = fwds[i + 1] if i + 1 < len(fwds) else None
-        ev_next = None
-        if nxt is not None:
-            nxt.run(SF.COUNT | SF.BIN)      # wide-workgroup kernels of set i + 1: in front of the backward of set i
-            front = torch.cuda.Event()
-            front.record(main)
-            with torch.cuda.stream(side):   # its compositing: beside that backward
-                side.wait_event(front)
-                nxt.run(SF.COMPOSITE)
-                ev_next = torch.cuda.Event()
-                ev_next.record(side)
-        if composited is not None:
-            main.wait_event(composited)
-        color = fwds[i].outputs[0]
-        dL = dL_dcolor_fn(v0, v1, color)
-        if want_means2D:
-            grads["means2D"] = m2d[v0:v1]
-        R.backward_views(fwds[i].state, dL, want_means2D=want_means2D, out=grads, accumulate=i > 0)
-        composited = ev_next
-    main.wait_stream(side)
+    try:
+        cur.run(SF.COUNT | SF.BIN | SF.COMPOSITE)
+        composited = None                   # event: compositing of the set whose backward comes next (None: it ran on `main`)
+        for i, (v0, v1) in enumerate(bounds):
+            nxt = staged(*bounds[i + 1]) if i + 1 < len(bounds) else None
+            ev_next = None
+            if nxt is not None:
+                nxt.run(SF.COUNT | SF.BIN)  # wide-workgroup kernels of set i + 1: in front of the backward of set i
+                front = torch.cuda.Event()
+                front.record(main)
+                with torch.cuda.stream(side):   # its compositing: beside that backward
+                    side.wait_event(front)
+                    nxt.run(SF.COMPOSITE)
+                    ev_next = torch.cuda.Event()
+                    ev_next.record(side)
+            if composited is not None:
+                main.wait_event(composited)
+            color = cur.outputs[0]
+            cur.make_current()              # rasterizer.last_header() / last_tile_count() inside the callback: THIS set's tables
+            dL = dL_dcolor_fn(v0, v1, color)
+            if want_means2D:
+                grads["means2D"] = m2d[v0:v1]
+            R.backward_views(cur.state, dL, want_means2D=want_means2D, out=grads, accumulate=i > 0)
+            hdrs[i].copy_(cur.header)
+            # set i is done on `main`, which also waited for its compositing on `side`: its buffers go back to the allocator
+            # (blocks of the caller's stream, reused by work queued behind this point)
+            cur, composited = nxt, ev_next
+    finally:
+        main.wait_stream(side)              # also when the callback or a launch raised: nothing of this call is left on `side`
     grads.pop("means2D", None)
     if want_means2D:
         grads["means2D"] = m2d
     if torch.cuda.is_current_stream_capturing():
         grads["num_rendered"] = -1
     else:
-        hdr = torch.stack([f.header for f in fwds]).cpu()          # the one host sync of the step
+        hdr = hdrs.cpu()                    # the one host sync of the step
         if bool((hdr[:, 1] != 0).any()):
             R.grow_capacity(2.0)
             return None                     # a set overflowed its binning capacity: the serial form re-sizes per call

@@ -590,6 +590,9 @@ class PipelinedRegistrationStep:
         ready, self._ready = getattr(self, "_ready", None), None
         prev, self._pending = self._pending, cur
         cur.launch(cam, gt_image, mask)
+        for s in self.steps:             # sparse_mask=None is settled ONCE, by the first mask either copy meets: both captures
+            if s._sparse is None and cur._sparse is not None:          # then run the same loss kernels
+                s._sparse = cur._sparse
         if prev is None:
             return ready                 # (a result the recovery below already collected, or None for the first call)
         out = prev.collect()

@@ -34,7 +34,9 @@ def _header_of(binb: torch.Tensor) -> torch.Tensor:
 
 def last_header() -> Optional[torch.Tensor]:
     """Device int64[2] = GgsBinHeader {num_rendered, overflow} of the most recent forward ISSUED BY THE CALLING THREAD
-    (aliases its workspace).  Per thread, like the pinned landing buffer: the guarded optimiser step of one thread must
+    (aliases its workspace).  Inside a dL_dcolor_fn callback of ggsplat.batch.fwd_bwd_views it is the forward whose images the
+    callback was handed, in every pipeline mode (the staged form, pipeline=2, has the NEXT set's stages queued by then:
+    StagedForward.make_current).  Per thread, like the pinned landing buffer: the guarded optimiser step of one thread must
     not read the overflow word of a forward that another thread (an eval worker) issued in between."""
     b = getattr(_pinned, "last_bin", None)
     return None if b is None else _header_of(b[0])
@@ -345,6 +347,7 @@ class StagedForward:
                       ptr(rotations), ptr(cov3D_precomp), ptr(view), ptr(proj), ptr(campos), ptr(tanfov), ptr(geom),
                       ptr(binb), cap, ptr(img), ptr(color), ptr(depth), ptr(alpha), ptr(radii))
         self.header = _header_of(binb)
+        self._last_bin = (binb, V, _lib.n_tiles(W, H), _tile_count_offset(L, prm, cap))
         st = self.state = ForwardState()
         st.prm, st.bg, st.means3D, st.shs, st.colors, st.opac = prm, bg, means3D, shs, colors_precomp, opacities
         st.scales, st.rots, st.cov, st.view, st.proj, st.campos, st.tanfov = scales, rotations, cov3D_precomp, view, proj, campos, tanfov
@@ -354,6 +357,20 @@ class StagedForward:
             _capture_headers.append(self.header)
 
     COUNT, BIN, COMPOSITE = 1, 2, 4
+
+    @property
+    def tile_count(self) -> Optional[torch.Tensor]:
+        """List lengths of the 16x16 tiles of THIS forward, int32 [V, T] (what last_tile_count() returns for a forward_views call)."""
+        if _lib.tile_size() != (16, 16):
+            return None
+        binb, V, T, off = self._last_bin
+        return binb[off:off + V * T * 4].view(torch.int32).reshape(V, T)
+
+    def make_current(self) -> None:
+        """Make this forward the calling thread's "most recent forward": last_header() / last_tile_count() then describe IT.
+        With stages of several forwards in flight the most recently ISSUED one is not the one a loss callback is about to
+        consume (ggsplat.batch sets it right before dL_dcolor_fn(i))."""
+        _pinned.last_bin = self._last_bin
 
     def run(self, stages: int) -> None:
         """Queue the given stages on PyTorch's current stream."""

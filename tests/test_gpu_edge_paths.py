@@ -266,7 +266,7 @@ def test_forward_stages_queued_one_by_one_equal_the_one_call_forward():
     for k in g1:
         assert rel_l1(g2[k], g1[k]) <= 2e-6, k
     L = _lib.lib()
-    for bad in (0, 8, -1, 16 | 1):
+    for bad in (0, 8, -1, 16 | 1, fwd.COUNT | fwd.COMPOSITE):      # the last: not a contiguous run
         assert L.ggs_forward_stages(bad, *fwd._args, _lib.stream_ptr(torch.device(dev))) != 0
         assert b"ggs_forward_stages" in L.ggs_last_error()
     # a shape that was never run through forward_views has no learnt binning capacity: refused, not guessed
@@ -274,3 +274,36 @@ def test_forward_stages_queued_one_by_one_equal_the_one_call_forward():
     with pytest.raises(_lib.GgsError, match="forward_views once"):
         R.StagedForward(t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None,
                         **{**kw, **{k: v[:1] for k, v in cams.items()}})
+
+
+def test_loss_callback_sees_the_tables_of_its_own_set_in_every_pipeline_mode():
+    """rasterizer.last_tile_count() / last_header() inside dL_dcolor_fn describe the forward whose images the callback was
+    handed -- serial, pipeline=1 and the staged form (pipeline=2), where the NEXT set's count + bin stages are already queued
+    when the callback runs (the region-of-interest loss would zero gradients in the wrong tiles otherwise)."""
+    from ggsplat import batch, rasterizer as R
+    sc, _ = small_scene(P=700, W=96, H=64, sh_degree=0, seed=5)
+    cams_l = S.orbit_cameras(6, width=96, img_height=64, fx=105.0, fy=105.0, cx=47.0, cy=33.0)
+    dev = "cuda"
+    t = {k: sc[k].to(dev) for k in ("means3D", "opacities", "shs", "scales", "rotations")}
+    cams = S.stack_cameras(cams_l, device=dev)
+    bg = torch.zeros(3, device=dev)
+    w = torch.randn(6, 3, 64, 96, generator=torch.Generator().manual_seed(9)).to(dev)
+    want = {}
+    for v0 in range(0, 6, 2):       # per launch set of two views: the list lengths of ITS forward
+        *_, st = R.forward_views(t["means3D"], t["opacities"], t["shs"], None, t["scales"], t["rotations"], None,
+                                 view=cams["view"][v0:v0 + 2], proj=cams["proj"][v0:v0 + 2], campos=cams["campos"][v0:v0 + 2],
+                                 tanfov=cams["tanfov"][v0:v0 + 2], bg=bg, W=96, H=64, sh_degree=0)
+        want[v0] = (R.bin_sections(st)["tile_count"].clone(), st.num_rendered)
+    assert not torch.equal(want[0][0], want[2][0])
+    for pipeline in (0, 1, 2):
+        seen = {}
+
+        def fn(v0, v1, color):
+            seen[v0] = (R.last_tile_count().clone(), R.last_header().clone())
+            return w[v0:v1]
+        batch.fwd_bwd_views(t, cams, bg=bg, W=96, H=64, sh_degree=0, dL_dcolor_fn=fn, chunk=2, pipeline=pipeline)
+        torch.cuda.synchronize()
+        assert sorted(seen) == [0, 2, 4], pipeline
+        for v0, (tc, hdr) in seen.items():
+            assert torch.equal(tc, want[v0][0]), (pipeline, v0)
+            assert int(hdr[0]) == want[v0][1] and int(hdr[1]) == 0, (pipeline, v0)

@@ -35,14 +35,14 @@ def scene():
     return inp, ck
 
 
-def _fwd(inp, ck, colors=None, bg=(0., 0., 0.), keep=False, views=slice(None), **over):
+def _fwd(inp, ck, colors=None, bg=(0., 0., 0.), keep=False, views=slice(None), debug=False, **over):
     from ggsplat import rasterizer as R
     a = {**inp, **over}
     dev = a["means3D"].device
     return R.forward_views(a["means3D"], a["opacities"], None, colors, a["scales"], a["rotations"], None,
                            view=ck["view"][views], proj=ck["proj"][views], campos=ck["campos"][views],
                            tanfov=ck["tanfov"][views], bg=torch.tensor(bg, device=dev), W=W, H=H, sh_degree=0,
-                           keep_state=keep)
+                           keep_state=keep, debug=debug)
 
 
 def test_partition_of_unity_and_sanity(scene):
@@ -153,6 +153,18 @@ def test_latency_mapping_equals_throughput_mapping_bitwise(scene):
     g8 = R.backward_views(st8, w.expand(8, 3, H, W).contiguous(), want_means2D=False)
     for k in ("means3D", "opacities", "colors_precomp", "scales", "rotations"):
         assert float((g1[k] * 8 - g8[k]).abs().sum() / g8[k].abs().sum()) < 1e-5, k
+    # debug mode (pipe.debug) arms the self-check of the per-quadrant walks: their LDS record slice is filled with NaNs in front of
+    # EVERY round (csrc/ggs_render.hip poison_slots), so a stale slot that reached an output -- the walks read one pair past the
+    # last entry of a round, rounds of odd, even and 64 entries all occur at this size -- would be a NaN here
+    cp, rp, dp, ap, stp = _fwd(inp, ck, colors=col, bg=(0.1, 0.2, 0.3), keep=True, views=slice(2, 3), debug=True)
+    assert torch.equal(cp, c1) and torch.equal(dp, d1) and torch.equal(ap, a1)
+    sp = R.img_sections(stp)
+    assert torch.equal(sp["final_T"], s1["final_T"]) and torch.equal(sp["n_contrib"], s1["n_contrib"])
+    n = st1.num_rendered
+    assert torch.equal(R.bin_sections(stp)["ids"][:n], R.bin_sections(st1)["ids"][:n])      # the narrowed quadrant masks too
+    gp = R.backward_views(stp, w, want_means2D=False)
+    for k in ("means3D", "opacities", "colors_precomp", "scales", "rotations"):
+        assert torch.isfinite(gp[k]).all() and float((gp[k] - g1[k]).abs().sum() / g1[k].abs().sum()) < 1e-5, k
 
 
 def test_one_view_against_the_c_oracle(scene):
