@@ -28,16 +28,35 @@ namespace {
 #define fail ggs_fail_
 
 // ---- optional per-kernel timing (bench.py roofline leg) ------------------------------------
-enum { K_PRE = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD, K_PRE_BWD, K_ORDER, K_COUNT };
+enum { K_PRE = 0, K_SCAN, K_SCATTER, K_SORT, K_RENDER_FWD, K_RENDER_BWD, K_PRE_BWD, K_ORDER, K_COUNT,
+       K_ZERO = K_COUNT };       // (the two zero fills: bracketed in the timestamp mode only -- ggs_profile_read keeps its eight values)
+// Second mode (ggs_profile_stamps): instead of host events, a one-lane kernel in front of and behind every bracketed kernel writes the
+// device's constant-rate clock into the caller's buffer.  Those are ordinary launches: they are CAPTURED with the step and replayed
+// with it, so the per-kernel intervals come from the replayed graph itself, not from eager launches with host events between them.
+#define GGS_MAX_STAMPS 4096
 struct Profile {
     bool on = false, have = false;
     hipEvent_t ev[K_COUNT][2];
     bool used[K_COUNT] = {};
     float ms[K_COUNT] = {};
+    unsigned long long* stamps = nullptr;       // device buffer, one slot per stamp
+    int stamp_cap = 0, n_stamps = 0;
+    short stamp_id[GGS_MAX_STAMPS];             // 2 kernel + (0 start | 1 stop)
 };
 thread_local Profile g_prof;
 
+__global__ void k_stamp(unsigned long long* slot) { *slot = wall_clock64(); }
+
+void prof_stamp(int id, hipStream_t s) {
+    Profile& p = g_prof;
+    if (p.n_stamps >= p.stamp_cap || p.n_stamps >= GGS_MAX_STAMPS) return;      // full: later stamps are dropped (the log says how many there are)
+    p.stamp_id[p.n_stamps] = (short)id;
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, s, p.stamps + p.n_stamps);
+    ++p.n_stamps;
+}
+
 void prof_start(int k, hipStream_t s) {
+    if (g_prof.stamps) { prof_stamp(2 * k, s); return; }
     if (!g_prof.on) return;
     if (!g_prof.have) {
         for (int i = 0; i < K_COUNT; ++i) { hipEventCreate(&g_prof.ev[i][0]); hipEventCreate(&g_prof.ev[i][1]); }
@@ -46,12 +65,13 @@ void prof_start(int k, hipStream_t s) {
     hipEventRecord(g_prof.ev[k][0], s);
 }
 void prof_stop(int k, hipStream_t s) {
+    if (g_prof.stamps) { prof_stamp(2 * k + 1, s); return; }
     if (!g_prof.on) return;
     hipEventRecord(g_prof.ev[k][1], s);
     g_prof.used[k] = true;
 }
 void prof_collect(hipStream_t s) {
-    if (!g_prof.on) return;
+    if (!g_prof.on || g_prof.stamps) return;
     hipStreamSynchronize(s);
     for (int i = 0; i < K_COUNT; ++i)
         if (g_prof.used[i]) { hipEventElapsedTime(&g_prof.ms[i], g_prof.ev[i][0], g_prof.ev[i][1]); g_prof.used[i] = false; }
@@ -155,6 +175,26 @@ int ggs_tile_size(int* width, int* height) {
 
 int ggs_profile_enable(int on) { g_prof.on = on != 0; return GGS_OK; }
 
+int ggs_profile_stamps(void* device_slots, int capacity) {
+    g_err[0] = 0;
+    if (device_slots && capacity <= 0) return fail(GGS_ERR_ARG, "ggs_profile_stamps: capacity=%d", capacity);
+    g_prof.stamps = (unsigned long long*)device_slots;
+    g_prof.stamp_cap = device_slots ? capacity : 0;
+    g_prof.n_stamps = 0;
+    return GGS_OK;
+}
+int ggs_profile_stamp_log(int* ids, int capacity, int* clock_khz) {
+    g_err[0] = 0;
+    if (clock_khz) {
+        int dev = 0, khz = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess)
+            return fail(GGS_ERR_HIP, "ggs_profile_stamp_log: no wall clock rate: %s", hipGetErrorString(hipGetLastError()));
+        *clock_khz = khz;
+    }
+    for (int i = 0; ids && i < g_prof.n_stamps && i < capacity; ++i) ids[i] = g_prof.stamp_id[i];
+    return g_prof.n_stamps;
+}
+
 int ggs_profile_read(float* ms, int n) {
     if (!ms || n < K_COUNT) return fail(GGS_ERR_ARG, "ggs_profile_read: need room for %d floats", (int)K_COUNT);
     for (int i = 0; i < K_COUNT; ++i) ms[i] = g_prof.ms[i];
@@ -183,13 +223,16 @@ int ggs_bin_layout(const GgsParams* p, size_t bin_capacity, size_t offsets[8]) {
     return GGS_OK;
 }
 
-int ggs_count_blends(const GgsParams* p, const void* geom, const void* bin, size_t bin_capacity, const void* img,
-                     unsigned long long* count, void* stream_) {
+}  // extern "C"
+
+namespace {
+int count_pairs_impl(const GgsParams* p, const void* geom, const void* bin, size_t bin_capacity, const void* img,
+                     unsigned long long* count, int n_out, void* stream_) {
     g_err[0] = 0;
     GGS_TRY(check_params(p));
     if (!geom || !bin || !img || !count) return fail(GGS_ERR_ARG, "ggs_count_blends: NULL pointer argument");
     hipStream_t s = (hipStream_t)stream_;
-    if (ggs_zero_async(count, 8, s) != hipSuccess) return fail(GGS_ERR_HIP, "ggs_count_blends: clearing the counter failed");
+    if (ggs_zero_async(count, 8 * (size_t)n_out, s) != hipSuccess) return fail(GGS_ERR_HIP, "ggs_count_blends: clearing the counter failed");
     if (p->P == 0) return GGS_OK;
     const Dims d = dims(p);
     const int V = p->n_views;
@@ -205,8 +248,44 @@ int ggs_count_blends(const GgsParams* p, const void* geom, const void* bin, size
     a.rec = (const SplatRec*)geom;
     a.n_contrib = (const uint32_t*)((const char*)img + ggs_align((size_t)V * p->W * p->H * 4));
     a.header = (const GgsBinHeader*)(b + L.header);
-    hipLaunchKernelGGL(ggs_k_count_blends, dim3((unsigned)a.n_items), dim3(64), 0, s, a, count);
+    hipLaunchKernelGGL(ggs_k_count_blends, dim3((unsigned)a.n_items), dim3(64), 0, s, a, count, n_out);
     return check("count_blends", s, p->debug);
+}
+}  // namespace
+
+extern "C" {
+int ggs_count_blends(const GgsParams* p, const void* geom, const void* bin, size_t bin_capacity, const void* img,
+                     unsigned long long* count, void* stream_) {
+    return count_pairs_impl(p, geom, bin, bin_capacity, img, count, 1, stream_);
+}
+int ggs_count_pairs(const GgsParams* p, const void* geom, const void* bin, size_t bin_capacity, const void* img,
+                    unsigned long long* counts4, void* stream_) {
+    return count_pairs_impl(p, geom, bin, bin_capacity, img, counts4, 4, stream_);
+}
+int ggs_count_forward_visits(const GgsParams* p, const void* geom, const void* bin, size_t bin_capacity,
+                             unsigned long long* counts3, void* stream_) {
+    g_err[0] = 0;
+    GGS_TRY(check_params(p));
+    if (!geom || !bin || !counts3) return fail(GGS_ERR_ARG, "ggs_count_forward_visits: NULL pointer argument");
+    hipStream_t s = (hipStream_t)stream_;
+    if (ggs_zero_async(counts3, 24, s) != hipSuccess) return fail(GGS_ERR_HIP, "ggs_count_forward_visits: clearing the counters failed");
+    if (p->P == 0) return GGS_OK;
+    const Dims d = dims(p);
+    const int V = p->n_views;
+    const BinLayout L = ggs_bin_layout(V, d.T, bin_capacity);
+    char* b = (char*)bin;
+    RenderArgs a;
+    memset(&a, 0, sizeof(a));
+    a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.n_items = V * d.T;
+    a.header = (const GgsBinHeader*)(b + L.header);
+    a.order = (const uint32_t*)(b + L.order);
+    a.tile_count = (const uint32_t*)(b + L.tile_count);
+    a.tile_offset = (const uint32_t*)(b + L.tile_offset);
+    a.view_base = (const unsigned long long*)(b + L.view_base);
+    a.ids = (uint32_t*)(b + L.ids);
+    a.rec = (const SplatRec*)geom;
+    hipLaunchKernelGGL(ggs_k_count_forward_visits, dim3((unsigned)a.n_items), dim3(64), 0, s, a, counts3);
+    return check("count_forward_visits", s, p->debug);
 }
 
 // Leading bytes of `bin` / of the backward's scratch that ggs_forward* / ggs_backward zero-fill first (what a
@@ -336,8 +415,10 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
 
     const dim3 gridP((unsigned)((p->P + 255) / 256), (unsigned)V);
     if (phases & PHASE_COUNT) {
+    if (g_prof.stamps) prof_stamp(2 * K_ZERO, s);
     if (ggs_zero_async(bin, L.zero_bytes, s) != hipSuccess)
         return fail(GGS_ERR_HIP, "ggs_forward: clearing the binning counters failed: %s", hipGetErrorString(hipGetLastError()));
+    if (g_prof.stamps) prof_stamp(2 * K_ZERO + 1, s);
     if (p->P > 0) {
         PreArgs a;
         a.P = p->P; a.K = p->K; a.deg = p->sh_degree; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T;
@@ -487,8 +568,10 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
     const char* b = (const char*)bin;
     const size_t HW = (size_t)p->W * p->H;
 
+    if (g_prof.stamps) prof_stamp(2 * K_ZERO, s);
     if (ggs_zero_async(scratch, (size_t)V * p->P * sizeof(GradRec), s) != hipSuccess)
         return fail(GGS_ERR_HIP, "ggs_backward: clearing the gradient records failed: %s", hipGetErrorString(hipGetLastError()));
+    if (g_prof.stamps) prof_stamp(2 * K_ZERO + 1, s);
     {
         RenderBwdArgs a;
         a.P = p->P; a.W = p->W; a.H = p->H; a.gx = d.gx; a.gy = d.gy; a.T = d.T; a.poison = p->debug;

@@ -122,7 +122,8 @@ __global__ void ggs_k_render_bwd(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_da(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_quad(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_da_quad(RenderBwdArgs a);
-__global__ void ggs_k_count_blends(RenderBwdArgs a, unsigned long long* out);
+__global__ void ggs_k_count_blends(RenderBwdArgs a, unsigned long long* out, int n_out);
+__global__ void ggs_k_count_forward_visits(RenderArgs a, unsigned long long* out);
 __global__ void ggs_k_preprocess_bwd_sh0(PreBwdArgs a);
 __global__ void ggs_k_preprocess_bwd_sh1(PreBwdArgs a);
 __global__ void ggs_k_preprocess_bwd_sh2(PreBwdArgs a);

@@ -63,8 +63,12 @@ __device__ __forceinline__ bool store_empty_tile(const RenderArgs& a, int v, int
 // a single view has ~1.1k non-empty tiles of ~300 splats for 1024 SIMDs and is bounded by the serial walk of its
 // longest tile -- is render_fwd_quadwave below; the backward keeps both mappings in one template.)
 // Same arithmetic per pixel, bit-identical results.
-__device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
+// CENSUS (ggs_k_count_forward_visits, a diagnostic: bench.py's evaluated-against-blended pair counts): the same walk with the
+// same tests on the lists as the binning left them, nothing stored -- it counts the quadrant passes it makes instead.
+template <bool CENSUS>
+__device__ __forceinline__ void render_fwd_body(const RenderArgs& a, unsigned long long* census = nullptr) {
     constexpr int NQ = GGS_NQ, q0 = 0;
+    unsigned n_visit = 0, n_blend = 0, n_entry = 0;
     // A forward that overflowed its binning capacity (only possible with a static capacity inside a captured graph) has no
     // lists: every tile is composited as EMPTY, so the outputs are deterministic (background, zero depth / alpha)
     // instead of uninitialised memory.  The overflow word tells the caller to re-run.
@@ -79,7 +83,8 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
     uint32_t* ids = a.ids + base;
     const float4* __restrict__ rec = reinterpret_cast<const float4*>(a.rec + (size_t)v * a.P);
 
-    if (L == 0 && store_empty_tile(a, v, ox, oy, lane)) return;
+    if (CENSUS && L == 0) return;
+    if (!CENSUS && L == 0 && store_empty_tile(a, v, ox, oy, lane)) return;
 
     float pxf[NQ], pyf[NQ], T[NQ], C0[NQ], C1[NQ], C2[NQ], D[NQ], A[NQ];
     uint32_t last[NQ];
@@ -131,15 +136,18 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
                 uint32_t posv;   // list position + 1, materialised in a VGPR once per splat (not once per quadrant)
                 asm volatile("v_mov_b32 %0, %1" : "=v"(posv) : "s"(first + j + 1));
                 const uint32_t act = word & live;
+                if (CENSUS) ++n_entry;
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
                     if (!(act & (1u << (GGS_ID_BITS + q0 + q)))) continue;                   // wave-uniform: scalar branch
+                    if (CENSUS) ++n_visit;
                     // predicated, branch-free per-pixel update: lane masks instead of nested exec juggling
                     const float dx = gx - pxf[q], dy = gy - pyf[q];
                     const float power = ggs_falloff_log2(cxx, cxy, cyy, dx, dy);
                     const float alpha = __builtin_fminf(GGS_ALPHA_MAX, op * __builtin_amdgcn_exp2f(power));
                     const uint64_t m_ok = __builtin_amdgcn_ballot_w64(power <= 0.f) & __builtin_amdgcn_ballot_w64(alpha >= GGS_ALPHA_MIN);
                     if (m_ok == 0) continue;
+                    if (CENSUS) ++n_blend;
                     const float wa = alpha * T[q];
                     const float test_T = T[q] - wa;           // = T (1 - alpha)
                     const uint64_t m_stop = m_ok & __builtin_amdgcn_ballot_w64(test_T < GGS_T_MIN);
@@ -168,8 +176,12 @@ __device__ __forceinline__ void render_fwd_body(const RenderArgs& a) {
             uint32_t neww = cur.w & GGS_ID_MASK;
 #pragma unroll
             for (int q = 0; q < NQ; ++q) neww |= ((uint32_t)(plane[q] >> lane) & 1u) << (GGS_ID_BITS + q);
-            if (lane < n) ids[first + lane] = neww;
+            if (!CENSUS && lane < n) ids[first + lane] = neww;
         }
+    }
+    if (CENSUS) {
+        if (lane == 0) { atomicAdd(census, (unsigned long long)n_visit); atomicAdd(census + 1, (unsigned long long)n_blend); atomicAdd(census + 2, (unsigned long long)n_entry); }
+        return;
     }
 
     const size_t HW = (size_t)a.H * a.W;
@@ -398,7 +410,10 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
 }  // namespace
 
 // K4b: grid V*T work items (x4 for the per-quadrant variant), block 64.
-__global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) { render_fwd_body(a); }
+__global__ __launch_bounds__(64) void ggs_k_render_fwd(RenderArgs a) { render_fwd_body<false>(a); }
+// out[0] quadrant passes (64 alpha tests each), out[1] passes in which some pixel passed the test, out[2] list entries walked.
+// Must run between the binning and the compositing of a forward: the compositing narrows the masks this walk reads.
+__global__ __launch_bounds__(64) void ggs_k_count_forward_visits(RenderArgs a, unsigned long long* out) { render_fwd_body<true>(a, out); }
 __global__ __launch_bounds__(64) void ggs_k_render_fwd_quad(RenderArgs a) { render_fwd_quadwave(a); }
 
 namespace {
@@ -655,7 +670,9 @@ __global__ __launch_bounds__(64) void ggs_k_render_bwd_da_quad(RenderBwdArgs a) 
 // Introspection (bench.py's compute-side roofline): the number of (splat, pixel) pairs the forward BLENDED, i.e. the pairs
 // the backward differentiates -- list position below the pixel's last contributor, falloff exponent <= 0, alpha >= 1/255 --
 // counted with the backward's own tests over the forward's lists.  One wave per work item; not on any timed path.
-__global__ __launch_bounds__(64) void ggs_k_count_blends(RenderBwdArgs a, unsigned long long* out) {
+// n_out >= 4 (ggs_count_pairs): out[1] quadrant passes of the backward (64 pixels evaluated each), out[2] entries it reduces (some
+// quadrant bit set), out[3] list entries it walks.
+__global__ __launch_bounds__(64) void ggs_k_count_blends(RenderBwdArgs a, unsigned long long* out, int n_out) {
     if (a.header->overflow) return;
     const uint32_t item = blockIdx.x;
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
@@ -681,6 +698,7 @@ __global__ __launch_bounds__(64) void ggs_k_count_blends(RenderBwdArgs a, unsign
     __shared__ float4 s_rec[64 * 3];
     RoundLds lds{s_rec};
     unsigned long long n = 0;
+    unsigned n_pass = 0, n_red = 0;
     for (int first = 0; first < maxc; first += 64) {
         const Rec3 cur = gather_round(rec, ids, first, L, lane);
         lds.put(cur, lane);
@@ -688,9 +706,11 @@ __global__ __launch_bounds__(64) void ggs_k_count_blends(RenderBwdArgs a, unsign
         for (int j = 0; j < cnt; ++j) {
             const uint32_t word = (uint32_t)__builtin_amdgcn_readlane((int)cur.w, j);
             const float4 ra = s_rec[j * 3 + 0], rb = s_rec[j * 3 + 1];
+            if (word & ~GGS_ID_MASK) ++n_red;
 #pragma unroll
             for (int q = 0; q < GGS_NQ; ++q) {
                 if (!(word & (1u << (GGS_ID_BITS + q)))) continue;
+                ++n_pass;
                 const float dx = ra.x - pxf[q], dy = ra.y - pyf[q];
                 const float power = ggs_falloff_log2(ra.z, ra.w, rb.x, dx, dy);
                 const float ar = __builtin_fminf(GGS_ALPHA_MAX, rb.y * __builtin_amdgcn_exp2f(power));
@@ -699,5 +719,9 @@ __global__ __launch_bounds__(64) void ggs_k_count_blends(RenderBwdArgs a, unsign
         }
     }
     if (lane == 0 && n) atomicAdd(out, n);
+    if (lane == 0 && n_out >= 4) {
+        atomicAdd(out + 1, (unsigned long long)n_pass); atomicAdd(out + 2, (unsigned long long)n_red);
+        atomicAdd(out + 3, (unsigned long long)maxc);
+    }
 }
 

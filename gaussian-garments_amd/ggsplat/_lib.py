@@ -90,8 +90,12 @@ _SIGS = {
     "ggs_visibility_scratch_bytes": (C.c_size_t, [C.c_int, C.c_int, C.c_size_t]),
     "ggs_visibility": (C.c_int, [C.c_int, C.c_int, C.c_int] + [_PTR] * 6 + [C.c_size_t, _PTR, _PTR, _PTR]),
     "ggs_count_blends": (C.c_int, [C.POINTER(GgsParams), _PTR, _PTR, C.c_size_t, _PTR, _PTR, _PTR]),
+    "ggs_count_pairs": (C.c_int, [C.POINTER(GgsParams), _PTR, _PTR, C.c_size_t, _PTR, _PTR, _PTR]),
+    "ggs_count_forward_visits": (C.c_int, [C.POINTER(GgsParams), _PTR, _PTR, C.c_size_t, _PTR, _PTR]),
     "ggs_profile_enable": (C.c_int, [C.c_int]),
     "ggs_profile_read": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
+    "ggs_profile_stamps": (C.c_int, [_PTR, C.c_int]),
+    "ggs_profile_stamp_log": (C.c_int, [C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_int)]),
     "ggs_last_error": (C.c_char_p, []),
     "ggs_version": (C.c_char_p, []),
     "ggs_build_id": (C.c_char_p, []),

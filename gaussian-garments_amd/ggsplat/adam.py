@@ -20,6 +20,34 @@ import torch
 from ._lib import check, lib, ptr, stream_ptr
 
 
+class _LrStaging:
+    """Pinned staging rows of GraphAdam.push_lr, used round robin, each with the event of its last upload: with iterations in
+    flight (PipelinedRegistrationStep has no per-iteration host sync) the next push must not rewrite a row whose copy has not
+    run yet.  A deep copy of the optimiser (tests clone whole models) gets fresh rows: events are not copyable."""
+    ROWS = 4
+
+    def __init__(self, n_groups: int):
+        self.n = n_groups
+        self.rows = torch.zeros(self.ROWS, n_groups, dtype=torch.float32).pin_memory()
+        self.events = [None] * self.ROWS
+        self.slot = 0
+
+    def __deepcopy__(self, memo):
+        return _LrStaging(self.n)
+
+    def next_row(self) -> torch.Tensor:
+        k = self.slot
+        self.slot = (k + 1) % self.ROWS
+        if self.events[k] is not None:
+            self.events[k].synchronize()          # the copy that last read this row (four pushes ago) has run
+        self._k = k
+        return self.rows[k]
+
+    def uploaded(self, dev) -> None:
+        ev = self.events[self._k] = self.events[self._k] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+
+
 class GraphAdam:
     def __init__(self, params: Iterable, lr: float = 0.0, betas=(0.9, 0.999), eps: float = 1e-15):
         groups = list(params)
@@ -39,11 +67,7 @@ class GraphAdam:
         L = lib()
         self._state_bytes = int(L.ggs_adam_state_bytes())
         self._lr_dev = torch.zeros(len(self.param_groups), dtype=torch.float32, device=dev)
-        # pinned staging rows of push_lr, used round robin, each with the event of its last upload: with iterations in flight
-        # (PipelinedRegistrationStep has no per-iteration host sync) the next push must not rewrite a row whose copy has not run
-        self._lr_host = torch.zeros(4, len(self.param_groups), dtype=torch.float32).pin_memory()
-        self._lr_ev = [None] * 4
-        self._lr_slot = 0
+        self._lr_host = _LrStaging(len(self.param_groups))
         self.state: Dict[torch.Tensor, Dict[str, torch.Tensor]] = {}
         for g in self.param_groups:
             for p in g["params"]:
@@ -58,16 +82,11 @@ class GraphAdam:
     def push_lr(self) -> None:
         """Upload param_groups[i]["lr"] to the device (call after changing a learning rate, outside a capture).  Asynchronous:
         the values take effect for the work queued AFTER this call on the current stream."""
-        k = self._lr_slot
-        self._lr_slot = (k + 1) % len(self._lr_ev)
-        if self._lr_ev[k] is not None:
-            self._lr_ev[k].synchronize()          # the copy that last read this row (four pushes ago) has run
-        row = self._lr_host[k]
+        row = self._lr_host.next_row()
         for i, g in enumerate(self.param_groups):
             row[i] = float(g["lr"])
         self._lr_dev.copy_(row, non_blocking=True)
-        ev = self._lr_ev[k] = self._lr_ev[k] or torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(self.device))
+        self._lr_host.uploaded(self.device)
 
     @property
     def step_count(self) -> int:

@@ -455,6 +455,8 @@ class GraphedRegistrationStep:
         if self._slack != 1.0:
             R.grow_capacity(self._slack)
             self._slack = 1.0
+        from . import profile
+        profile.restart_if_active()          # a timestamp profile (ggsplat.profile) logs the captured launches only, not the warm-up's
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph), warnings.catch_warnings():
             warnings.filterwarnings("ignore", message="The AccumulateGrad node's stream does not match")   # capture stream

@@ -431,12 +431,33 @@ int ggs_visibility(int P, int F, int n_verts, const float* verts, const int64_t*
  * preprocess_bwd, order_tiles} and returns the count (8). */
 int ggs_profile_enable(int on);
 int ggs_profile_read(float* ms, int n);
+/* Timestamp mode of the same aid (round 6): while `device_slots` (device memory, `capacity` x 8 bytes) is set on the calling thread,
+ * ggs_forward* / ggs_backward launch a one-lane kernel in front of and behind every kernel they bracket (the eight above + their two
+ * zero fills) that stores the device's constant-rate clock (hipDeviceAttributeWallClockRate) into the next slot.  These are ordinary
+ * launches on `stream`: a caller that captures its step into a hipGraph captures them too, and every replay refreshes the slots -- the
+ * per-kernel intervals then come from the replayed graph itself, launch gaps included, instead of from eager launches with host events
+ * between them.  ggs_profile_stamps(NULL, 0) ends the mode; it also restarts the slot numbering.  ggs_profile_stamp_log copies out what
+ * each slot written so far is -- 2 k for the start, 2 k + 1 for the end of kernel k in the order of ggs_profile_read, k = 8: a zero
+ * fill --, stores the clock rate in kHz, and returns the number of slots used.  Not part of the reference's interface. */
+int ggs_profile_stamps(void* device_slots, int capacity);
+int ggs_profile_stamp_log(int* ids, int capacity, int* clock_khz);
 
 /* Introspection (bench.py's compute-side roofline; not part of the reference's interface): *count (device, 8 bytes) <-
  * the number of (Gaussian, pixel) pairs the forward that filled geom / bin / img blended = the pairs its backward
  * differentiates.  Walks the forward's lists with the backward's own tests; a few hundred microseconds, never on a timed path. */
 int ggs_count_blends(const GgsParams* p, const void* geom, const void* bin, size_t bin_capacity, const void* img,
                      unsigned long long* count, void* stream);
+/* Evaluated against blended work of the two compositing kernels (bench.py reports the ratio per kernel; VERDICT r5 #1c).
+ * ggs_count_pairs: counts4 (device, 32 bytes) <- {blended pairs as ggs_count_blends, quadrant passes of the backward (64 pixels
+ * evaluated each), list entries it reduces, list entries it walks}, from a COMPLETED forward.
+ * ggs_count_forward_visits: counts3 (device, 24 bytes) <- {quadrant passes of the forward (64 alpha tests each), passes in which
+ * some pixel passed the test (those run the blend), list entries walked}; it repeats the forward's walk on the lists as the binning
+ * left them, so it must run BETWEEN GGS_STAGE_BIN and GGS_STAGE_COMPOSITE of a ggs_forward_stages sequence (the compositing narrows
+ * the quadrant masks in place).  Neither is on a timed path. */
+int ggs_count_pairs(const GgsParams* p, const void* geom, const void* bin, size_t bin_capacity, const void* img,
+                    unsigned long long* counts4, void* stream);
+int ggs_count_forward_visits(const GgsParams* p, const void* geom, const void* bin, size_t bin_capacity,
+                             unsigned long long* counts3, void* stream);
 
 /* Thread-local message of the last failing call on this thread ("" if none). */
 const char* ggs_last_error(void);

@@ -5,6 +5,7 @@
 #   sq     SQ instruction / wave-cycle counters (one --pmc pass, kernel-trace only)               -> gpurun_out/TAG_sq
 #   lds    LDS pipe: instructions, busy / stall / bank-conflict cycles (one --pmc pass)
 #   valu   VALU busy / lane activity: raw counters, then rocprofv3's derived VALUBusy / VALUUtilization (two --pmc passes)
+#   atomic, vmem   L2 atomic requests / tag stalls; vector-memory instructions and what the waves wait for (round 6; generic tables)
 #   fetch, write   FETCH_SIZE and WRITE_SIZE in SEPARATE --pmc passes (TCC slots; MI355X_MICROARCH.md, HBM section)
 # No other tracing domain is ever combined with --pmc.  The build id of the library is recorded beside the results;
 # tools/profile_summary.py turns the .db files into the tables under profiles/ (only for the passes that ran).
@@ -34,12 +35,14 @@ for p in $PASSES; do
     valu)  pmc_pass valu SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_BUSY_CYCLES
            pmc_pass valud VALUBusy VALUUtilization ;;
     lds)   pmc_pass lds SQ_WAVES SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES ;;
+    atomic) pmc_pass atomic TCC_ATOMIC_sum TCC_REQ_sum TCC_BUSY_sum TCC_TAG_STALL_sum ;;      # L2 side of the float atomics (round 6)
+    vmem)  pmc_pass vmem SQ_WAVES SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VMEM SQ_BUSY_CYCLES ;;
     fetch) pmc_pass fetch FETCH_SIZE ;;
     write) pmc_pass write WRITE_SIZE ;;
   esac
 done
 # summarise on the box and drop the databases: the merge back into gpurun_out/ is capped at 64 MiB
 python $R/tools/profile_summary.py $TAG $R/gpurun_out/prof_${TAG} $WORKLOAD || true
-rm -rf ${OUT}_trace ${OUT}_sq ${OUT}_lds ${OUT}_valu ${OUT}_valud ${OUT}_fetch ${OUT}_write
+rm -rf ${OUT}_trace ${OUT}_sq ${OUT}_lds ${OUT}_valu ${OUT}_valud ${OUT}_fetch ${OUT}_write ${OUT}_atomic ${OUT}_vmem
 for f in ${OUT}_*.log; do tail -5 $f > $f.tail; rm -f $f; done
 ls -la $R/gpurun_out | grep ${TAG} | head -20

@@ -74,6 +74,31 @@ def lds_table(path, out, header):
                     f"{100 * idx / max(g('SQ_BUSY_CYCLES'), 1.0):.1f} |\n")
 
 
+def generic_table(path, out, header):
+    """Any --pmc pass: every collected counter per launch of each kernel of this library, beside the kernel's duration."""
+    cur = sqlite3.connect(path).cursor()
+    rows, names = {}, []
+    for name, counter, n, total in cur.execute(
+            "select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
+        m = re.match(r"(ggs_k_\w+|\(anonymous namespace\)::k_\w+)", name)
+        if m:
+            rows.setdefault(m.group(1), {})[counter] = (n, total)
+            if counter not in names:
+                names.append(counter)
+    dur = {}
+    for name, avg in cur.execute("select name, avg(end-start) from kernels group by name"):
+        m = re.match(r"(ggs_k_\w+|\(anonymous namespace\)::k_\w+)", name)
+        if m:
+            dur[m.group(1)] = avg / 1e3
+    names.sort()
+    with open(out, "w") as f:
+        f.write(header)
+        f.write("| kernel | launches | " + " | ".join(n + " / launch" for n in names) + " | kernel us |\n|---|---|" + "---|" * (len(names) + 1) + "\n")
+        for k, c in sorted(rows.items()):
+            n = max(v[0] for v in c.values())
+            f.write(f"| {k} | {n} | " + " | ".join(f"{c.get(x, (1, 0.0))[1] / n:.4g}" for x in names) + f" | {dur.get(k, 0):.1f} |\n")
+
+
 def valu_table(path, prefix, bid, bargs, workload, derived_path=None):
     """VALUBusy = 100 sum(SQ_ACTIVE_INST_VALU) / CU_NUM / max(GRBM_GUI_ACTIVE) and VALUUtilization = 100 sum(SQ_THREAD_CYCLES_VALU)
     / (sum(SQ_ACTIVE_INST_VALU) 64) -- rocprofiler-sdk's own gfx950 formulas (counter_defs.yaml), evaluated per kernel."""
@@ -142,6 +167,13 @@ def main(tag, prefix, workload):
     u = db(tag, "valu")
     if u:
         valu_table(u, prefix, bid, bargs, workload, db(tag, "valud"))
+    for kind, what in (("atomic", "L2 atomic requests"), ("vmem", "vector-memory instructions and wave waits")):
+        a = db(tag, kind)
+        if a:
+            generic_table(a, prefix + f"_{kind}_counters.md",
+                          f"# {what} (rocprofv3 --pmc, one pass, kernel-trace only), build {bid}\n\n`python bench.py --cpu-views 0 "
+                          f"--loop-views 0 --extra-configs 0 {bargs} --pipeline 0 --steps 1 --warmup 0 --views {os.environ.get('PMC_VIEWS', '32')}`; "
+                          f"SQ cycle counters are in quad-cycles.\n\n")
     fe, wr = db(tag, "fetch"), db(tag, "write")
     if fe and wr:
         hbm_summary.main(fe, wr, prefix + "_hbm_traffic", int(os.environ.get("PMC_VIEWS", "32")), bid, workload)
