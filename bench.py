@@ -235,12 +235,13 @@ def main():
     bounds = [round(i * len(my) / n_parts) for i in range(n_parts + 1)]
     part_cams = [{k: v[bounds[i]:bounds[i + 1]] for k, v in cams.items()} for i in range(n_parts)]
 
-    def compute(part=0):
+    def compute(part=0, pipeline=None):
         """Everything of a step that runs on this GPU alone, for one slice of this rank's views: mesh binding, fwd+bwd of
         the slice in launch sets of `chunk`, gradient accumulation, mesh-binding backward (ggsplat.batch.model_fwd_bwd_views:
         the C entry points without the autograd graph).  Returns the flat gradient bucket [mesh.v | _xyz | f_dc | f_rest |
         opacity | scaling | rotation] the step's all-reduce works on; the per-tensor gradients are views of it."""
-        r = batch.model_fwd_bwd_views(model, part_cams[part], bg=bg, W=W, H=H, chunk=chunk, pipeline=int(args.pipeline),
+        r = batch.model_fwd_bwd_views(model, part_cams[part], bg=bg, W=W, H=H, chunk=chunk,
+                                      pipeline=int(args.pipeline if pipeline is None else pipeline),
                                       want_means2D=bool(args.means2d), dL_dcolor_fn=lambda v0, v1, color: dL_buf[:v1 - v0])
         stats["means2D"] = r.get("means2D")
         stats["num_rendered"] = r["num_rendered"] + (stats.get("num_rendered", 0) if part else 0)
@@ -355,45 +356,163 @@ def main():
                               "pipeline": int(args.pipeline), "means2d": int(args.means2d), "graph": graph["g"] is not None,
                               "all_reduce_parts": n_parts}), flush=True)
     elif rank == 0:
-        # ---- per-kernel durations (HIP events on the launch stream, one launch set of `chunk` views) ----
+        # ---- per-kernel durations, (a) HIP events on the launch stream around every kernel of EVERY launch set of the step ----
         L = _lib.lib()
         from ggsplat import rasterizer as R
+        from ggsplat.profile import DeviceStamps, NAMES as STAMP_NAMES
         model.update_face_coor()
         with torch.no_grad():
             inputs = dict(means3D=model.get_xyz.detach(), scales=model.get_scaling.detach(),
                           rotations=model.get_rotation.detach(), opacities=model.get_opacity.detach(),
                           shs=model.get_features.detach())
-        cs = {k: v[:chunk] for k, v in cams.items()}
-        reps, acc_ms = 5, [0.0] * len(KERNELS)
+        sets = [(v0, min(len(my), v0 + chunk)) for v0 in range(0, len(my), chunk)]
+        reps, acc_ms = 3, [0.0] * len(KERNELS)
+        per_set = [{"views": [v0, v1], "render_fwd_ms": 0.0, "render_bwd_ms": 0.0} for v0, v1 in sets]
+        P_vis_sum = N_sum = contrib_sum = 0.0
         L.ggs_profile_enable(1)
-        P_vis = N_chunk = 0
-        for _ in range(reps):
-            color, radii, depth, alpha, st = R.forward_views(
-                inputs["means3D"], inputs["opacities"], inputs["shs"], None, inputs["scales"], inputs["rotations"], None,
-                view=cs["view"], proj=cs["proj"], campos=cs["campos"], tanfov=cs["tanfov"], bg=bg, W=W, H=H,
-                sh_degree=args.sh_degree)
-            buf = (C.c_float * 8)()
-            L.ggs_profile_read(buf, 8)
-            fwd_ms = list(buf)[:5]
-            order_ms = buf[7]
-            R.backward_views(st, dL_buf[:chunk], want_means2D=bool(args.means2d))
-            L.ggs_profile_read(buf, 8)
-            ms = fwd_ms + list(buf)[5:7] + [order_ms]
-            acc_ms = [a + b for a, b in zip(acc_ms, ms)]
-            P_vis = float((radii > 0).sum().item()) / chunk
-            N_chunk = st.num_rendered
-            # blended splats per pixel (n_contrib = position of the last contributor in the tile's list)
-            nc = R.img_sections(st)["n_contrib"]
-            mean_contrib = float(nc.float().mean().item())
-            # (Gaussian, pixel) pairs the forward blended = the useful work of both render kernels (ggs_count_blends)
-            cnt = torch.zeros(1, dtype=torch.int64, device=dev)
-            _lib.check(L.ggs_count_blends(C.byref(st.prm), st.geom.data_ptr(), st.bin.data_ptr(), st.cap, st.img.data_ptr(),
-                                          cnt.data_ptr(), C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "ggs_count_blends")
-            pairs_view = float(cnt.item()) / chunk
-            del st
+        for rep in range(reps):
+            for si, (v0, v1) in enumerate(sets):
+                cs = {k: v[v0:v1] for k, v in cams.items()}
+                color, radii, depth, alpha, st = R.forward_views(
+                    inputs["means3D"], inputs["opacities"], inputs["shs"], None, inputs["scales"], inputs["rotations"], None,
+                    view=cs["view"], proj=cs["proj"], campos=cs["campos"], tanfov=cs["tanfov"], bg=bg, W=W, H=H,
+                    sh_degree=args.sh_degree)
+                buf = (C.c_float * 8)()
+                L.ggs_profile_read(buf, 8)
+                fwd_ms = list(buf)[:5]
+                order_ms = buf[7]
+                R.backward_views(st, dL_buf[:v1 - v0], want_means2D=bool(args.means2d))
+                L.ggs_profile_read(buf, 8)
+                ms = fwd_ms + list(buf)[5:7] + [order_ms]
+                acc_ms = [a + b for a, b in zip(acc_ms, ms)]
+                per_set[si]["render_fwd_ms"] += ms[4] / reps
+                per_set[si]["render_bwd_ms"] += ms[5] / reps
+                if rep == 0:
+                    per_set[si]["num_rendered_per_view"] = round(st.num_rendered / (v1 - v0), 1)
+                    P_vis_sum += float((radii > 0).sum().item())
+                    N_sum += st.num_rendered
+                    # blended splats per pixel (n_contrib = position of the last contributor in the tile's list)
+                    contrib_sum += float(R.img_sections(st)["n_contrib"].float().mean().item()) * (v1 - v0)
+                del st
         L.ggs_profile_enable(0)
+        n_mine = len(my)
+        # milliseconds per STEP of this rank (all its launch sets), per kernel
         kern_ms = {k: v / reps for k, v in zip(KERNELS, acc_ms)}
-        N_view = N_chunk / chunk
+        N_view, P_vis, mean_contrib = N_sum / n_mine, P_vis_sum / n_mine, contrib_sum / n_mine
+
+        # ---- (b) evaluated against blended work of the two compositing kernels, ring by ring (not timed) --------------------
+        # forward: quadrant passes = 64 alpha tests each (ggs_count_forward_visits, between binning and compositing of a staged
+        # forward); backward: quadrant passes = 64 pixels evaluated each, blended pairs = the pairs that are differentiated
+        # (ggs_count_pairs on the completed forward; the blended count is checked against the C oracle's in tests/)
+        ring = 32 if n_mine % 32 == 0 and world == 1 else chunk
+        census = []
+        for v0 in range(0, n_mine, ring):
+            v1 = min(n_mine, v0 + ring)
+            cs = {k: v[v0:v1] for k, v in cams.items()}
+            R.forward_views(inputs["means3D"], inputs["opacities"], inputs["shs"], None, inputs["scales"], inputs["rotations"], None,
+                            view=cs["view"], proj=cs["proj"], campos=cs["campos"], tanfov=cs["tanfov"], bg=bg, W=W, H=H,
+                            sh_degree=args.sh_degree, keep_state=False)      # (learns the binning capacity of this launch shape)
+            sf = R.StagedForward(inputs["means3D"], inputs["opacities"], inputs["shs"], None, inputs["scales"], inputs["rotations"], None,
+                                 view=cs["view"], proj=cs["proj"], campos=cs["campos"], tanfov=cs["tanfov"], bg=bg, W=W, H=H,
+                                 sh_degree=args.sh_degree)
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            c3, c4 = torch.zeros(3, dtype=torch.int64, device=dev), torch.zeros(4, dtype=torch.int64, device=dev)
+            sf.run(sf.COUNT | sf.BIN)
+            stc = sf.state
+            _lib.check(L.ggs_count_forward_visits(C.byref(stc.prm), stc.geom.data_ptr(), stc.bin.data_ptr(), stc.cap, c3.data_ptr(), stream),
+                       "ggs_count_forward_visits")
+            sf.run(sf.COMPOSITE)
+            _lib.check(L.ggs_count_pairs(C.byref(stc.prm), stc.geom.data_ptr(), stc.bin.data_ptr(), stc.cap, stc.img.data_ptr(),
+                                         c4.data_ptr(), stream), "ggs_count_pairs")
+            f3, b4, nv = c3.tolist(), c4.tolist(), v1 - v0
+            if int(sf.header[1]) != 0:
+                continue
+            census.append({"views": [v0, v1], "list_entries_per_view": round(int(sf.header[0]) / nv, 1),
+                           "blended_pairs_per_view": round(b4[0] / nv, 1),
+                           "fwd_evaluated_pairs_per_view": round(64.0 * f3[0] / nv, 1), "fwd_blend_pass_pairs_per_view": round(64.0 * f3[1] / nv, 1),
+                           "fwd_entries_walked_per_view": round(f3[2] / nv, 1),
+                           "bwd_evaluated_pairs_per_view": round(64.0 * b4[1] / nv, 1), "bwd_entries_reduced_per_view": round(b4[2] / nv, 1),
+                           "bwd_entries_walked_per_view": round(b4[3] / nv, 1)})
+            del sf, stc
+        tot_v = sum(c["views"][1] - c["views"][0] for c in census) or 1
+
+        def cmean(key):
+            return sum(c[key] * (c["views"][1] - c["views"][0]) for c in census) / tot_v
+        pairs_view = cmean("blended_pairs_per_view") if census else 0.0
+        work = None
+        if census:
+            work = {"note": "(Gaussian, pixel) pairs per view, means over all views of the step; evaluated = 64 x quadrant passes of the "
+                            "kernel, blended = pairs the forward blended (= the pairs the backward differentiates)",
+                    "render_fwd": {"evaluated": round(cmean("fwd_evaluated_pairs_per_view"), 1), "blended": round(pairs_view, 1),
+                                   "blended_over_evaluated": round(pairs_view / max(cmean("fwd_evaluated_pairs_per_view"), 1.0), 4),
+                                   "blend_pass_pairs": round(cmean("fwd_blend_pass_pairs_per_view"), 1),
+                                   "entries_walked": round(cmean("fwd_entries_walked_per_view"), 1)},
+                    "render_bwd": {"evaluated": round(cmean("bwd_evaluated_pairs_per_view"), 1), "blended": round(pairs_view, 1),
+                                   "blended_over_evaluated": round(pairs_view / max(cmean("bwd_evaluated_pairs_per_view"), 1.0), 4),
+                                   "entries_reduced": round(cmean("bwd_entries_reduced_per_view"), 1),
+                                   "entries_walked": round(cmean("bwd_entries_walked_per_view"), 1)},
+                    "by_ring" if ring == 32 else "by_launch_set": census}
+
+        # ---- (c) the same kernels timed INSIDE the replayed graph: device timestamps captured with the step (ggsplat.profile) -----
+        # The serial step (launch sets one after the other: intervals on two streams would overlap) is captured once more with a
+        # one-lane timestamp kernel in front of and behind every kernel the library brackets, and replayed; next to it the same
+        # serial step without the stamps.  kernel sum + what lies between the brackets = first-to-last-stamp span, by construction.
+        in_graph = None
+        if not args.no_graph and n_parts == 1:
+            try:
+                def timed_replays(g, n):
+                    g.replay()
+                    torch.cuda.synchronize(dev)
+                    t1 = time.perf_counter()
+                    for _ in range(n):
+                        g.replay()
+                    torch.cuda.synchronize(dev)
+                    return (time.perf_counter() - t1) / n * 1e3
+                R.pop_capture_headers()
+                g_plain = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_plain, capture_error_mode="thread_local"):
+                    compute(0, pipeline=0)
+                stamps = DeviceStamps(dev).start()
+                g_st = torch.cuda.CUDAGraph()
+                try:
+                    with torch.cuda.graph(g_st, capture_error_mode="thread_local"):
+                        compute(0, pipeline=0)
+                finally:
+                    stamps.stop()
+                R.pop_capture_headers()
+                serial_ms = timed_replays(g_plain, 20)
+                inst_ms = timed_replays(g_st, 5)
+                n_rep = 10
+                sec = {k: 0.0 for k in STAMP_NAMES}
+                span = between = 0.0
+                bwd_launch = []
+                for _ in range(n_rep):
+                    g_st.replay()
+                    torch.cuda.synchronize(dev)
+                    r = stamps.read()
+                    for k in STAMP_NAMES:
+                        sec[k] += r["seconds"][k] / n_rep
+                    span += r["span"] / n_rep
+                    between += r["between_brackets"] / n_rep
+                    bwd_launch = [a + b / n_rep for a, b in zip(bwd_launch or [0.0] * len(r["per_launch"]["render_bwd"]), r["per_launch"]["render_bwd"])]
+                ksum = sum(sec.values())
+                in_graph = {"kernel_ms_per_step": {k: round(v * 1e3, 4) for k, v in sec.items()},
+                            "kernel_sum_ms_per_step": round(ksum * 1e3, 3),
+                            "between_brackets_ms_per_step": round(between * 1e3, 3),
+                            "first_to_last_stamp_ms": round(span * 1e3, 3),
+                            "instrumented_step_ms": round(inst_ms, 3), "serial_step_ms": round(serial_ms, 3),
+                            "serial_step_over_kernel_sum": round(serial_ms / (ksum * 1e3), 4),
+                            "stamps_per_step": r["n_stamps"], "stamps_dropped": getattr(stamps, "dropped", 0),
+                            "render_bwd_ms_per_launch_set": [round(x * 1e3, 4) for x in bwd_launch],
+                            "note": "device clock stamps (one-lane kernels) captured inside the replayed SERIAL step, mean of 10 replays; an "
+                                    "interval holds the kernel and the launch gaps on both sides of it up to the stamps; between_brackets = mesh "
+                                    "binding, PyTorch glue kernels and the gaps between brackets; serial_step_ms = the same graph without stamps"}
+                del g_plain, g_st
+            except Exception as e:                   # a measurement aid must never cost the line
+                print(f"[bench] in-graph timestamps skipped: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                torch.cuda.synchronize(dev)
+                R.pop_capture_headers()
+
         T = ((W + 15) // 16) * ((H + 15) // 16)
         B = alg_bytes(Fn, K, P_vis, N_view, W * H, T)
         group_ms = {"preprocess": kern_ms["preprocess"],
@@ -401,21 +520,27 @@ def main():
                     "render_fwd": kern_ms["render_fwd"], "render_bwd": kern_ms["render_bwd"],
                     "preprocess_bwd": kern_ms["preprocess_bwd"]}
         dom = max(("render_fwd", "render_bwd", "preprocess", "preprocess_bwd"), key=lambda k: group_ms[k])
-        dom_bytes = B[dom] * chunk
-        achieved = dom_bytes / (group_ms[dom] * 1e-3) / 1e9
+        # the dominant kernel's AVERAGE LAUNCH: its time per step / launch sets per step -- from the replayed graph's own stamps when
+        # they were taken (the timed region's form), else from the HIP events around the eager launches
+        launches = len(sets)
+        dom_step_ms = in_graph["kernel_ms_per_step"][dom] if in_graph else group_ms[dom]
+        dom_launch_ms = dom_step_ms / launches
+        dom_bytes = B[dom] * n_mine / launches            # algorithmic bytes of an average launch (mean views per launch x per-view bytes)
+        achieved = dom_bytes / (dom_launch_ms * 1e-3) / 1e9
         B_view = sum(B.values())
         # HBM bytes per launch from the PMC counters (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE in separate passes,
         # tools/hbm_traffic.sh -> profiles/rNN_hbm_traffic.json; bench.py cannot run a profiler on itself).  A collection
         # is only used when it was taken from THIS build (same ggs_build_id) and this workload; otherwise null.
         traffic, traffic_src = None, None
         bid = _lib.build_id()
+        views_per_launch = n_mine / launches
         for fn in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.json")), reverse=True):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 wl = tj.get("workload", {})
                 if tj.get("build_id") == bid and wl == {"P": Fn, "W": W, "H": H, "sh_degree": args.sh_degree}:
                     traffic = int(tj["kernels"]["ggs_k_" + dom + ("_sh%d" % args.sh_degree if dom == "preprocess_bwd" else "")]
-                                  ["traffic"] / tj["views_per_launch"] * chunk)
+                                  ["traffic"] / tj["views_per_launch"] * views_per_launch)
                     traffic_src = "profiles/" + fn
                     break
             except Exception:
@@ -432,15 +557,30 @@ def main():
                             "lane_activity_pct": round(kv.get("rocprof_lane_activity_pct") or kv["lane_activity_pct"], 1),
                             "source": "profiles/" + fn}
                     valu["busy_pct"] = valu["rocprof_VALUBusy_pct"]     # (key kept for readers of earlier rounds' lines)
-                    # issue utilisation: SQ_INSTS_VALU of the launch x the kernel's average issue cycles per instruction /
-                    # (SIMDs x clock x THIS run's kernel time) -- rocprofv3's derived VALUBusy reads > 100 % on this part
-                    # (VERDICT r4), this figure cannot
+                    # COUNTER-DERIVED: everything below comes from the committed PMC pass alone.
+                    #   in_flight_over_simd_cycles = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE per XCD) -- rocprofiler's own
+                    #     VALUBusy formula; SQ_ACTIVE_INST_VALU sums, over the waves, the quad-cycles a wave has a VALU instruction IN
+                    #     FLIGHT, and the in-flight windows of the waves sharing a SIMD overlap (issue every ~3.4 cycles, in flight ~4.2):
+                    #     a value >= 1 says the SIMDs never lack a VALU instruction in flight, it is not an occupancy of issue slots;
+                    #   cycles_in_flight_per_inst = 4 x SQ_ACTIVE_INST_VALU / SQ_INSTS_VALU (measured, per instruction);
+                    #   effective_clock_ghz = GRBM_GUI_ACTIVE / kernel time of the profiled pass.
+                    # The issue-slot MODEL of earlier rounds (instructions x hand-priced issue cycles, VALU_CYCLES_PER_INST) is kept
+                    # beside them under its own name; model / counter = priced issue cycles / measured in-flight cycles.
+                    if kv.get("valu_insts_per_launch") and kv.get("gui_active_cycles_per_launch") and kv.get("active_inst_valu_per_launch"):
+                        act4 = 4.0 * kv["active_inst_valu_per_launch"]
+                        valu["counter_derived"] = {
+                            "in_flight_over_simd_cycles": round(act4 / (N_SIMD * kv["gui_active_cycles_per_launch"]), 4),
+                            "cycles_in_flight_per_inst": round(act4 / kv["valu_insts_per_launch"], 3),
+                            "effective_clock_ghz": None if not kv.get("kernel_us") else round(kv["gui_active_cycles_per_launch"] / (kv["kernel_us"] * 1e3), 3)}
                     cyc = VALU_CYCLES_PER_INST.get(dom)
                     if cyc and kv.get("valu_insts_per_launch"):
-                        insts = kv["valu_insts_per_launch"] / vj["views_per_launch"] * chunk
-                        valu["insts_per_wave_note"] = "SQ_INSTS_VALU (wave-instructions) of the committed collection, scaled to this launch"
-                        valu["issue_cycles_per_inst"] = cyc
-                        valu["issue_util"] = round(insts * cyc / (N_SIMD * CLOCK_GHZ * 1e9 * group_ms[dom] * 1e-3), 4)
+                        insts = kv["valu_insts_per_launch"] / vj["views_per_launch"] * views_per_launch
+                        valu["issue_cycles_per_inst_model"] = cyc
+                        valu["issue_util_model"] = round(insts * cyc / (N_SIMD * CLOCK_GHZ * 1e9 * dom_launch_ms * 1e-3), 4)
+                        valu["issue_util"] = valu["issue_util_model"]      # (earlier rounds' key)
+                        valu["issue_util_note"] = ("MODEL: SQ_INSTS_VALU of the committed collection x hand-priced issue cycles per instruction "
+                                                   "(tools/isa_audit.py x profiles/r02_valu_issue_rates.md) / (1024 SIMDs x 2.4 GHz x this run's kernel "
+                                                   "time); the counter-only figures are under counter_derived")
                     break
             except Exception:
                 continue
@@ -450,34 +590,42 @@ def main():
         # every collection so far has shown VALU-saturated), else "hbm".  achieved / peak / frac stay the HBM figures the
         # contract asks for.
         flops_pair = {"render_fwd": FWD_FLOPS_PER_PAIR, "render_bwd": BWD_FLOPS_PER_PAIR}.get(dom)
-        compute = None
-        if flops_pair is not None:
-            tf = pairs_view * chunk * flops_pair / (group_ms[dom] * 1e-3) / 1e12
-            compute = {"useful_pairs_per_view": round(pairs_view, 1), "flops_per_pair": flops_pair,
-                       "achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS,
-                       "frac": round(tf / FP32_VECTOR_PEAK_TFLOPS, 5),
-                       "lanes_useful_pct": None if valu is None else valu["lane_activity_pct"],
-                       "note": "blended (Gaussian, pixel) pairs from ggs_count_blends; flops per pair counted from the kernel source"}
+        compute_side = None
+        if flops_pair is not None and pairs_view:
+            tf = pairs_view * n_mine * flops_pair / (dom_step_ms * 1e-3) / 1e12
+            compute_side = {"useful_pairs_per_view": round(pairs_view, 1), "flops_per_pair": flops_pair,
+                            "achieved_TFLOPs": round(tf, 2), "peak_TFLOPs": FP32_VECTOR_PEAK_TFLOPS,
+                            "frac": round(tf / FP32_VECTOR_PEAK_TFLOPS, 5),
+                            "lanes_useful_pct": None if valu is None else valu["lane_activity_pct"],
+                            "note": "blended (Gaussian, pixel) pairs from ggs_count_pairs, mean over all views of the step; flops per pair counted from the kernel source"}
         bound = "valu" if ((valu is not None and valu["busy_pct"] > 90.0) or (valu is None and flops_pair is not None)) else "hbm"
-        # the two halves of the line: per-kernel HIP-event times x launches per step against the measured step.  The events
-        # bracket every kernel of an EAGER launch set (record + wait around each one), which reads 2-4 % longer than the same
-        # kernels inside the replayed graph: in a rocprofv3 trace of this command the GPU is busy 99.6 % of the step and the
-        # kernel durations sum to the step (profiles/r05_pipeline_overlap.md, --pipeline 0) -- nothing overlaps, nothing idles
-        launches = -(-len(my) // chunk)
-        ksum = sum(kern_ms.values()) * launches
+        # The two halves of the line.  kernel_sum_ms_per_step: HIP events around every kernel of every launch set of an EAGER step
+        # (a record + wait around each launch reads a few percent long); in_graph: the same kernels stamped inside the replayed
+        # serial graph -- its kernel sum + between_brackets IS the stamp span, and serial_step_ms is that graph without the stamps.
+        # ms_per_step (the headline) is the pipelined form of the same step (launch sets on two streams: config.launch_set_pipeline).
+        ksum = sum(kern_ms.values())
         roofline = {"bound": bound, "kernel": "ggs_k_" + dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                     # counter bytes / kernel time / peak: what the HBM pipe actually carries while the dominant kernel runs
-                    "traffic_frac": None if traffic is None else round(traffic / (group_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "traffic_frac": None if traffic is None else round(traffic / (dom_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                    "launch_ms_source": "device timestamps inside the replayed graph (in_graph), mean over the step's launch sets" if in_graph
+                    else "HIP events around the eager launches, mean over the step's launch sets",
                     "kernel_sum_ms_per_step": round(ksum, 3), "launches_per_step": launches,
-                    "step_over_kernel_sum": round(dt / args.steps * 1e3 / ksum, 4),
-                    "kernel_sum_note": "event-bracketed eager kernels x launches per step (mesh binding and the 3 zero fills not "
-                                       "included); < 1: the graph-replayed step is shorter than the sum of its event-timed kernels",
+                    "step_over_kernel_sum": round((in_graph["serial_step_ms"] / (in_graph["kernel_sum_ms_per_step"] + in_graph["between_brackets_ms_per_step"]))
+                                                  if in_graph else dt / args.steps * 1e3 / ksum, 4),
+                    "step_over_event_kernel_sum": round(dt / args.steps * 1e3 / ksum, 4),
+                    "kernel_sum_note": "kernel_sum_ms_per_step / kernel_ms_per_step: HIP events around every kernel of all launch sets of an "
+                                       "eager step (mesh binding and PyTorch glue not included); step_over_kernel_sum: serial replayed step / "
+                                       "(in-graph kernel sum + between-bracket time) when the stamps were taken, else ms_per_step / event sum",
                     "traffic_source": traffic_src if traffic is not None else
                     f"none: no profiles/*_hbm_traffic.json was collected from build {bid} on this workload",
-                    "valu": valu, "compute": compute, "launch_views": chunk, "launch_ms": round(group_ms[dom], 4),
+                    "valu": valu, "compute": compute_side, "work": work, "in_graph": in_graph,
+                    "launch_views": round(views_per_launch, 2), "launch_ms": round(dom_launch_ms, 4),
+                    "launch_ms_events": round(group_ms[dom] / launches, 4),
                     "alg_bytes_per_launch": int(dom_bytes),
-                    "kernel_ms_per_launch": {k: round(v, 4) for k, v in kern_ms.items()},
+                    "kernel_ms_per_step": {k: round(v, 4) for k, v in kern_ms.items()},
+                    "kernel_ms_per_launch": {k: round(v / launches, 4) for k, v in kern_ms.items()},
+                    "per_launch_set": per_set,
                     # B_ref: the same lower bound with the reference algorithm's global radix sort of 64-bit
                     # (tile | depth) keys in place of the per-tile sort: N (12 + 24 ceil((32 + ceil(log2 T)) / 8))
                     "whole_path": {"alg_bytes_per_view": int(B_view),

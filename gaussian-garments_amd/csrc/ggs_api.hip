@@ -40,7 +40,7 @@ struct Profile {
     bool used[K_COUNT] = {};
     float ms[K_COUNT] = {};
     unsigned long long* stamps = nullptr;       // device buffer, one slot per stamp
-    int stamp_cap = 0, n_stamps = 0;
+    int stamp_cap = 0, n_stamps = 0, n_dropped = 0;
     short stamp_id[GGS_MAX_STAMPS];             // 2 kernel + (0 start | 1 stop)
 };
 thread_local Profile g_prof;
@@ -49,7 +49,7 @@ __global__ void k_stamp(unsigned long long* slot) { *slot = wall_clock64(); }
 
 void prof_stamp(int id, hipStream_t s) {
     Profile& p = g_prof;
-    if (p.n_stamps >= p.stamp_cap || p.n_stamps >= GGS_MAX_STAMPS) return;      // full: later stamps are dropped (the log says how many there are)
+    if (p.n_stamps >= p.stamp_cap || p.n_stamps >= GGS_MAX_STAMPS) { ++p.n_dropped; return; }      // full: counted, not written
     p.stamp_id[p.n_stamps] = (short)id;
     hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, s, p.stamps + p.n_stamps);
     ++p.n_stamps;
@@ -180,7 +180,7 @@ int ggs_profile_stamps(void* device_slots, int capacity) {
     if (device_slots && capacity <= 0) return fail(GGS_ERR_ARG, "ggs_profile_stamps: capacity=%d", capacity);
     g_prof.stamps = (unsigned long long*)device_slots;
     g_prof.stamp_cap = device_slots ? capacity : 0;
-    g_prof.n_stamps = 0;
+    g_prof.n_stamps = g_prof.n_dropped = 0;
     return GGS_OK;
 }
 int ggs_profile_stamp_log(int* ids, int capacity, int* clock_khz) {
@@ -192,7 +192,7 @@ int ggs_profile_stamp_log(int* ids, int capacity, int* clock_khz) {
         *clock_khz = khz;
     }
     for (int i = 0; ids && i < g_prof.n_stamps && i < capacity; ++i) ids[i] = g_prof.stamp_id[i];
-    return g_prof.n_stamps;
+    return g_prof.n_stamps + g_prof.n_dropped;        // stamps ATTEMPTED: more than the slot capacity means the tail was dropped
 }
 
 int ggs_profile_read(float* ms, int n) {

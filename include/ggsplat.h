@@ -438,7 +438,8 @@ int ggs_profile_read(float* ms, int n);
  * per-kernel intervals then come from the replayed graph itself, launch gaps included, instead of from eager launches with host events
  * between them.  ggs_profile_stamps(NULL, 0) ends the mode; it also restarts the slot numbering.  ggs_profile_stamp_log copies out what
  * each slot written so far is -- 2 k for the start, 2 k + 1 for the end of kernel k in the order of ggs_profile_read, k = 8: a zero
- * fill --, stores the clock rate in kHz, and returns the number of slots used.  Not part of the reference's interface. */
+ * fill --, stores the clock rate in kHz, and returns the number of stamps ATTEMPTED since the mode was set (more than the capacity: the
+ * tail was not written).  Not part of the reference's interface. */
 int ggs_profile_stamps(void* device_slots, int capacity);
 int ggs_profile_stamp_log(int* ids, int capacity, int* clock_khz);
 

@@ -109,6 +109,11 @@ def valu_table(path, prefix, bid, bargs, workload, derived_path=None):
         m = re.match(r"(ggs_k_\w+)", name)
         if m:
             rows.setdefault(m.group(1), {})[counter] = (n, total, mx)
+    dur = {}
+    for name, avg in cur.execute("select name, avg(end-start) from kernels group by name"):
+        m = re.match(r"(ggs_k_\w+)", name)
+        if m:
+            dur[m.group(1)] = avg / 1e3
     CU, XCD = 256, 8                      # GRBM_GUI_ACTIVE arrives summed over the 8 XCDs; the formula wants the max = sum / 8
     derived = {}
     if derived_path:                      # rocprofv3 evaluating its own derived metrics (per dispatch; averaged here)
@@ -131,7 +136,11 @@ def valu_table(path, prefix, bid, bargs, workload, derived_path=None):
             busy = 100.0 * act / CU / gui
             util = 100.0 * g("SQ_THREAD_CYCLES_VALU") / (act * 64.0)
             out["kernels"][k] = {"valu_busy_pct": round(busy, 2), "lane_activity_pct": round(util, 2), "valu_insts_per_launch": g("SQ_INSTS_VALU") / n,
-                                 "gui_active_cycles_per_launch": gui / n}
+                                 "gui_active_cycles_per_launch": gui / n,
+                                 # raw inputs of bench.py's counter-derived figures (round 6): quad-cycles with a VALU instruction in flight,
+                                 # summed over the waves; SIMD-busy quad-cycles; the kernel's duration in THIS (profiled) pass
+                                 "active_inst_valu_per_launch": g("SQ_ACTIVE_INST_VALU") / n, "sq_busy_cycles_per_launch": g("SQ_BUSY_CYCLES") / n,
+                                 "kernel_us": dur.get(k)}
             dv = derived.get(k, {})
             if dv:
                 out["kernels"][k].update(rocprof_valu_busy_pct=dv.get("VALUBusy"), rocprof_lane_activity_pct=dv.get("VALUUtilization"))
