@@ -182,14 +182,48 @@ def spawn_ranks(args):
     return subprocess.call(cmd, env=env)
 
 
+def error_line(args, exc, stage):
+    """The ONE JSON line of a run that could not be measured (rank 0 only): same leading keys, value null, the reason in `error` --
+    an unattended multi-GPU run that dies in RCCL's initialisation must leave something a reader can parse, not a traceback."""
+    import traceback
+    tb = traceback.extract_tb(exc.__traceback__)
+    where = f"{os.path.basename(tb[-1].filename)}:{tb[-1].lineno}" if tb else "?"
+    return {"metric": "fwd+bwd views/sec @1080p, 100k mesh-Gaussians", "value": None, "unit": "views/s",
+            "n_gpus": int(os.environ.get("WORLD_SIZE", args.gpus)), "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "error": f"{stage}: {type(exc).__name__}: {exc}"[:2000], "error_at": where,
+            "config": {"backend": "rccl" if args.backend == "nccl" else args.backend, "views_per_step": args.views}}
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))
+    stage = ["start-up"]
+    if int(os.environ.get("RANK", "0")) == 0 and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        # the launcher ends the surviving ranks with SIGTERM when one of them fails: rank 0 still leaves its line
+        import signal
+
+        def on_term(signum, frame):
+            print(json.dumps(error_line(args, RuntimeError("terminated by the launcher (SIGTERM): another rank failed or the run "
+                                                           "was cancelled"), stage[0])), flush=True)
+            os._exit(1)
+        signal.signal(signal.SIGTERM, on_term)
+    try:
+        run(args, stage)
+    except SystemExit:
+        raise
+    except BaseException as e:                   # noqa: BLE001 -- every failure becomes a parsable line on rank 0, then the traceback
+        if int(os.environ.get("RANK", "0")) == 0:
+            print(json.dumps(error_line(args, e, stage[0])), flush=True)
+        raise
+
+
+def run(args, stage):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.pipeline is None:       # +1 % on one GPU; a multi-rank run (never measured on hardware) keeps the plain serial launch sets
-        args.pipeline = 1 if world == 1 else 0
+    if args.pipeline is None:       # +1 % on one GPU; the same default for every world size since round 6 (a rank of 8 has ONE launch set and
+        args.pipeline = 1           # is unaffected; 2 / 4 ranks have 2 / 1: rehearsed on one device, tests/test_gpu_bench_ranks.py)
     if world != args.gpus:
         raise SystemExit(f"bench: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -198,10 +232,18 @@ def main():
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
     if world > 1:
+        stage[0] = f"init_process_group({args.backend})"
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(args.backend)
+        # the first collective is where an RCCL that cannot reach its peers fails: do it here, under its own name
+        stage[0] = f"first all-reduce ({args.backend}, {world} ranks)"
+        probe = torch.ones(1, device=dev)
+        dist.all_reduce(probe)
+        if int(probe.item()) != world:
+            raise RuntimeError(f"all-reduce of ones over {world} ranks returned {probe.item()}")
+    stage[0] = "building the scene"
 
     from ggsplat import batch, synthetic as S
     from ggsplat import _lib
@@ -290,6 +332,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    stage[0] = "eager priming step"
     try:
         step()                               # eager priming (untimed): learns the binning capacity
     except Exception as e:                   # a second stream that misbehaves must not cost the line: serial launch sets
@@ -300,8 +343,10 @@ def main():
         torch.cuda.synchronize(dev)
         step()
     if not args.no_graph:
+        stage[0] = "graph capture"
         torch.cuda.synchronize(dev)
         capture()
+    stage[0] = "warm-up / timed steps"
     for _ in range(args.warmup):
         step()
     sync()
@@ -349,6 +394,7 @@ def main():
         torch.save(torch.cat([g.reshape(-1) for g in stats["grads"]]).cpu(), args.dump_grads)
 
     out = None
+    stage[0] = "per-kernel / baseline legs"
     if args.timing_only:
         if rank == 0:
             print(json.dumps({"value": round(views_per_sec, 2), "unit": "views/s", "ms_per_step": round(dt / args.steps * 1e3, 3),

@@ -134,3 +134,46 @@ def test_two_rank_bucket_against_the_oracle_at_config3_size(tmp_path):
     assert float(flat.abs().sum()) > 0
     for name, e in errs.items():
         assert e <= 1e-4, (name, e)
+
+
+def _full_size(extra, tmp_path, name, timeout=1500):
+    dump = str(tmp_path / f"{name}.pt")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--cpu-views", "0", "--loop-views", "0",
+                        "--extra-configs", "0", "--dump-grads", dump] + extra, capture_output=True, text=True, timeout=timeout, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0]), torch.load(dump)
+
+
+def test_eight_and_seven_ranks_at_the_real_shape_on_one_device(tmp_path):
+    """The shape the driver's 8-GPU run has, rehearsed on ONE device over gloo: BASELINE configs[2] in full -- 100 000
+    Gaussians, 160 views of 1920x1080 --, `python bench.py --gpus 8` spawning its own ranks, 20 views per rank in ONE launch set, the
+    compute part captured into a hipGraph, one all-reduce of the flat bucket, the overflow flag and the capture-failed flag reduced
+    over the ranks.  Then SEVEN ranks: shards of 23 and 22 views (views[rank::7]), so the flag / timing reductions and the launch
+    sets see uneven shards.  The reduced bucket must equal the one-process 160-view bucket (fp32 summation order only), and the line
+    must carry the contract's keys with every rank listed."""
+    one, g1 = _full_size(["--gpus", "1"], tmp_path, "one")
+    assert one["n_gpus"] == 1 and one["config"]["views_per_step"] == 160 and float(g1.abs().sum()) > 0
+    for world, shards in ((8, [20] * 8), (7, [23, 23, 23, 23, 23, 23, 22])):
+        many, g = _full_size(["--gpus", str(world), "--backend", "gloo", "--single-device"], tmp_path, f"w{world}")
+        assert many["n_gpus"] == world and many["scaling"] == "strong" and many["config"]["views_per_step"] == 160
+        assert [r["rank"] for r in many["config"]["ranks"]] == list(range(world))
+        assert [r["views"] for r in many["config"]["ranks"]] == shards
+        assert many["config"]["views_per_launch"] == min(40, shards[0]) and many["config"]["collective"] == "one all-reduce per step"
+        assert many["value"] > 0 and many["roofline"]["kernel"] == "ggs_k_render_bwd" and many["cpu_baseline"] is None
+        assert many["roofline"]["in_graph"] is not None and many["roofline"]["launches_per_step"] == 1
+        assert g.shape == g1.shape
+        rel = float((g1.double() - g.double()).abs().sum() / g1.double().abs().sum())
+        assert rel < 2e-6, (world, rel)
+
+
+def test_two_ranks_with_pipelined_launch_sets(tmp_path):
+    """Two ranks x 80 views = two launch sets per rank, software-pipelined over a second stream inside each rank's captured
+    graph (the default of every world size since round 6), against the serial launch sets and against one rank."""
+    one, g1 = _full_size(["--gpus", "1", "--pipeline", "0"], tmp_path, "one_serial")
+    two, g2 = _full_size(["--gpus", "2", "--backend", "gloo", "--single-device"], tmp_path, "two_default")
+    assert two["config"]["launch_set_pipeline"] == 1 and [r["views"] for r in two["config"]["ranks"]] == [80, 80]
+    rel = float((g1.double() - g2.double()).abs().sum() / g1.double().abs().sum())
+    assert rel < 2e-6, rel

@@ -6,7 +6,7 @@ import ctypes as C
 import pytest
 import torch
 
-from helpers import small_scene
+from helpers import rel_l1, small_scene
 from ggsplat import synthetic as S
 
 pytestmark = pytest.mark.gpu
@@ -82,7 +82,7 @@ def test_device_stamps_eager_and_inside_a_replayed_graph():
         assert r["launches"][k] >= 1 and 0.0 < r["seconds"][k] < 0.05, k
     assert 0.0 < sum(r["seconds"].values()) <= r["span"] and r["between_brackets"] >= 0.0
     for k in ref:
-        assert torch.allclose(g1[k], ref[k], rtol=1e-4, atol=1e-6), k           # the stamps change nothing
+        assert rel_l1(g1[k], ref[k]) <= 1e-5, k           # the stamps change nothing (float atomics: summation order only)
     # after stop() nothing is stamped any more
     before = st.slots.clone()
     step()
@@ -107,7 +107,7 @@ def test_device_stamps_eager_and_inside_a_replayed_graph():
         assert rr["launches"]["render_bwd"] == 1 and 0.0 < rr["seconds"]["render_bwd"] < 0.05
         assert abs(sum(rr["seconds"].values()) + rr["between_brackets"] - rr["span"]) < 1e-9
     for k in ref:
-        assert torch.allclose(out[k], ref[k], rtol=1e-4, atol=1e-6), k
+        assert rel_l1(out[k], ref[k]) <= 1e-5, k
     # capacity too small: later stamps are dropped, the log says how many there were
     st = DeviceStamps(DEV, capacity=4).start()
     step()

@@ -223,6 +223,34 @@ def test_bench_launches_its_own_ranks(monkeypatch):
     assert "WORLD_SIZE=1" in str(e.value.code)
 
 
+def test_bench_failure_is_one_json_line_with_an_error_field():
+    """A run that cannot be measured (here: no GPU in the CPU container, so the very first device call fails; on an 8-GPU node
+    the same path catches an RCCL that cannot initialise) prints ONE parsable JSON line on rank 0 -- leading keys of the contract,
+    value null, the reason and the stage in `error` -- and exits non-zero (VERDICT r5 #6)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a machine without a GPU to provoke the failure")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    assert p.returncode != 0
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["value"] is None and d["n_gpus"] == 1 and d["unit"] == "views/s" and d["metric"].startswith("fwd+bwd views/sec")
+    assert d["error"].startswith("start-up: ") and "error_at" in d
+    # a rank other than 0 prints nothing
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--steps", "1"], capture_output=True,
+                       text=True, timeout=300, env={**env, "WORLD_SIZE": "2", "RANK": "1", "LOCAL_RANK": "1", "MASTER_ADDR": "127.0.0.1",
+                                                     "MASTER_PORT": "29999"})
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+
+
 def test_ctypes_mirrors_of_the_abi_structs_have_the_c_layout(tmp_path):
     """GgsParams / GgsStepPrologue / GgsStepTail are filled in Python and read in C: sizes and field offsets must agree
     (include/ggsplat.h compiled by gcc against the ctypes.Structure mirrors of ggsplat/_lib.py)."""
