@@ -681,7 +681,7 @@ def run(args, stage):
                                    "frac": round(B_view * views_per_sec / 1e9 / HBM_PEAK_GBS, 5)}}
 
         # ---- per-view drop-in loop (render() + autograd, one camera per call like the reference) ----
-        loop_vps = step_vps = graph_vps = pipe_vps = s3_vps = sil_vps = sil_frac = None
+        loop_vps = step_vps = graph_vps = pipe_vps = s3_vps = sil_vps = sil_frac = replica_rates = None
         if args.loop_views > 0 and world == 1:
             from ggsplat.render import render
             from types import SimpleNamespace
@@ -772,6 +772,33 @@ def run(args, stage):
             sil_sparse = bool(sstep.steps[0]._sparse)
             del sstep
             model.optimizer = None
+
+            # REPLICA MODE: R independent registrations, each with the reference's own one-step-per-view semantics, each
+            # with its own model / optimiser / captured iteration / stream, replayed side by side (ggsplat.inner_step.
+            # ReplicaRegistrationSteps).  Aggregate iterations per second over all replicas; R = 1 is the sequential captured step.
+            from ggsplat.inner_step import ReplicaRegistrationSteps
+            replica_rates = {}
+            try:
+                for R_n in (1, 2, 4, 8):
+                    ms_ = []
+                    for r_i in range(R_n):
+                        mr = MeshGaussianModel.from_tensors(verts, faces, S.skirt_gaussian_params(Fn, sh_degree=args.sh_degree, seed=r_i),
+                                                            sh_degree=args.sh_degree, device=dev)
+                        mr.training_setup(DEFAULT_OPT, is_ff=True)
+                        mr.optimizer = GraphAdam(mr.optimizer.param_groups, lr=0.0, eps=1e-15)
+                        ms_.append(mr)
+                    rsteps = ReplicaRegistrationSteps(ms_, W, H, bg)
+                    nl = len(lcams)
+
+                    def rpass():
+                        for i in range(nl):
+                            idx = [(i + 5 * r_i) % nl for r_i in range(R_n)]
+                            rsteps([lcams[k] for k in idx], [gts[k] for k in idx], [gt_mask] * R_n)
+                    replica_rates[str(R_n)] = round(rate(rpass, nl * R_n), 2)
+                    del rsteps, ms_
+            except Exception as e:           # a secondary line must never cost the headline line
+                print(f"[bench] replica line skipped: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+                torch.cuda.synchronize(dev)
 
             # the s3 iteration in its config-4 form (s3_appearance.py:107-149): texel-bound Gaussians (barycentric origins),
             # SH degree 3, ~50 % visible (mask applied to the opacities inside the captured step), get_final_xyz and SH
@@ -928,6 +955,9 @@ def run(args, stage):
             # salt-and-pepper mask, kept for comparison across rounds): the loss's first pass skips the masked-out boxes
             "s2_pipelined_graph_step_silhouette_mask": None if sil_vps is None else {
                 "iters_per_sec": round(sil_vps, 2), "mask_ones_frac": round(sil_frac, 4), "sparse_loss_pass": sil_sparse},
+            # R independent registrations replayed side by side on R streams of ONE GPU, aggregate iterations / s (reference semantics:
+            # one optimiser step per view in every replica; ggsplat.inner_step.ReplicaRegistrationSteps); "1" = one replica
+            "s2_replica_steps_iters_per_sec": replica_rates,
             # config-4 FORM of the s3 iteration (texel-bound Gaussians, K = 16, vis mask, five-term loss, Adam) with a two-tensor
             # stand-in for the StyleUNet: a rasterizer + loss + optimiser number, not a config-4 number
             "s3_graph_step_standin_net_iters_per_sec": None if s3_vps is None else round(s3_vps, 2),

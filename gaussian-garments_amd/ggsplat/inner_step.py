@@ -6,7 +6,7 @@ Density control (s2_registration.py:310-322) is ggsplat.densify; a captured step
 from __future__ import annotations
 
 from types import SimpleNamespace
-from typing import Callable, Dict, Optional
+from typing import List, Callable, Dict, Optional
 
 import torch
 import torch.nn.functional as F
@@ -613,6 +613,61 @@ class PipelinedRegistrationStep:
         if out is None:
             out = self._recover(cur, None)
         return out
+
+
+class ReplicaRegistrationSteps:
+    """R INDEPENDENT registrations on one GPU, each with the reference's own semantics -- one optimiser step per rendered view
+    (s2_registration.py:241-251, :326) -- replayed side by side: replica r owns a model, an optimiser, its workspaces, its captured
+    iteration (GraphedRegistrationStep) and a stream of its own.
+
+    Strict reference semantics cannot be spread over views (iteration i + 1 reads the parameters iteration i wrote: SURVEY 8e
+    "replicas only"), and ONE such iteration leaves most of an MI355X idle: a single 1080p view is ~1 100 non-empty tiles = 4 400
+    quadrant waves for 1 024 SIMDs, and the kernels are as long as their dozen longest walks.  Independent
+    problems -- the frames of several sequences, several subjects, a hyper-parameter sweep -- fill that idle time: every call queues
+    one iteration of every replica on the replica's stream (one hipGraphLaunch each, ~12 us of host time) and then collects the R
+    results; the GPU interleaves the R graphs.  On 8 GPUs the same thing runs as 8 x R replicas with no collective at all.
+
+    Each replica's arithmetic is exactly that of its solo GraphedRegistrationStep: same kernels on the same inputs; results differ
+    from a solo run only by the order of the float atomics inside the render backward, as two solo runs differ from each other
+    (tests/test_gpu_graph_step.py::test_replicas_follow_their_solo_trajectories)."""
+
+    def __init__(self, models, W: int, H: int, bg, **kw):
+        kw["lean"] = True
+        self.models = list(models)
+        dev = self.models[0]._xyz.device
+        self.streams = [torch.cuda.Stream(device=dev) for _ in self.models]
+        self.steps: List[GraphedRegistrationStep] = []
+        for m, s in zip(self.models, self.streams):
+            s.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(s):
+                self.steps.append(GraphedRegistrationStep(m, W, H, bg, **kw))
+
+    def __len__(self) -> int:
+        return len(self.steps)
+
+    @property
+    def recaptures(self) -> int:
+        return sum(s.recaptures for s in self.steps)
+
+    def __call__(self, cams, gt_images, masks=None) -> List[Dict[str, float]]:
+        """One iteration of EVERY replica: cams[r], gt_images[r] (and masks[r]) go to replica r.  Returns the R loss dictionaries."""
+        R_ = len(self.steps)
+        masks = [None] * R_ if masks is None else masks
+        for st, s, c, g, m in zip(self.steps, self.streams, cams, gt_images, masks):
+            with torch.cuda.stream(s):
+                st.launch(c, g, m)
+        outs = []
+        for st, s in zip(self.steps, self.streams):
+            out = st.collect()
+            if out is None:              # this replica's forward overflowed its static capacity (nothing was updated): the sequential
+                with torch.cuda.stream(s):                          # form grows the capacity, re-captures and repeats the iteration
+                    out = st(*st._last_args)
+            outs.append(out)
+        return outs
+
+    def synchronize(self) -> None:
+        for s in self.streams:
+            s.synchronize()
 
 
 class GraphedAppearanceStep(GraphedRegistrationStep):

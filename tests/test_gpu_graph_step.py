@@ -467,6 +467,72 @@ def test_pipelined_registration_step_matches_the_sequential_replay(slack):
             assert float((x - y).abs().mean()) <= 5e-3 and bool(torch.isfinite(x).all())
 
 
+def test_replicas_follow_their_solo_trajectories():
+    """ReplicaRegistrationSteps: three independent registrations (different parameter jitters, different camera orders), each with the
+    reference's one-step-per-view semantics, replayed side by side on three streams.  Every replica must follow the trajectory of
+    the SAME problem run alone through GraphedRegistrationStep: same kernels on the same inputs, so the two differ by the order of
+    the float atomics in the render backward and by nothing else -- the bound is what two SOLO runs of one problem differ by
+    (measured here), not bit identity, which the float atomics do not give a solo run either.  A capacity far too small for
+    replica 1 exercises the overflow recovery beside replicas that keep running."""
+    from ggsplat.inner_step import DEFAULT_OPT, GraphedRegistrationStep, ReplicaRegistrationSteps
+    from ggsplat.mesh_gaussian_model import MeshGaussianModel
+    v, f, params, cams, gts, masks = _scene(seed=4)
+    W_, H_ = cams[0].image_width, cams[0].image_height
+    bg = torch.zeros(3, device="cuda")
+    R_, n = 3, 6
+
+    def model(r):
+        g = torch.Generator().manual_seed(100 + r)
+        p = {k: (t + 0.01 * torch.randn(t.shape, generator=g) if k in ("_scaling", "_opacity") else t) for k, t in params.items()}
+        m = MeshGaussianModel.from_tensors(v, f, p, sh_degree=0, device="cuda")
+        m.training_setup(DEFAULT_OPT, is_ff=True)
+        return m
+
+    def view(r, i):
+        k = (i + 2 * r) % len(cams)
+        return cams[k], gts[k], masks[k]
+
+    def solo(r):
+        m = model(r)
+        st = GraphedRegistrationStep(m, W_, H_, bg)
+        return m, [st(*view(r, i)) for i in range(n)]
+    solos = [solo(r) for r in range(R_)]
+    twin0, twin0_losses = solo(0)                       # the run-to-run noise of a solo run
+    models = [model(r) for r in range(R_)]
+    reps = ReplicaRegistrationSteps(models, W_, H_, bg)
+    assert len(reps) == R_ and len({s.cuda_stream for s in reps.streams}) == R_
+    losses = [[] for _ in range(R_)]
+    for i in range(n):
+        c, g, m = zip(*[view(r, i) for r in range(R_)])
+        for r, out in enumerate(reps(c, g, m)):
+            losses[r].append(out)
+    reps.synchronize()
+    assert reps.recaptures == 0
+
+    def dist(ma, mb):
+        return max(float((pa.detach() - pb.detach()).abs().mean()) for pa, pb in zip(ma.parameters(), mb.parameters()) if pa.numel())
+    noise = dist(solos[0][0], twin0)
+    for r in range(R_):
+        for a, b in zip(solos[r][1], losses[r]):
+            assert abs(a["loss"] - b["loss"]) <= 1e-5 * abs(a["loss"]) + 1e-7, r
+        assert dist(solos[r][0], models[r]) <= max(4.0 * noise, 1e-5), (r, noise)
+    # replicas are different problems: their parameters differ by far more than the noise
+    assert dist(models[0], models[1]) > 100 * max(noise, 1e-7)
+    # overflow recovery of ONE replica (capacity cut to 0.2 % at its capture) beside two that run normally
+    from ggsplat import rasterizer as Rz
+    models2 = [model(r) for r in range(R_)]
+    reps2 = ReplicaRegistrationSteps(models2, W_, H_, bg)
+    reps2.steps[1]._slack = 0.002
+    for i in range(n):
+        c, g, m = zip(*[view(r, i) for r in range(R_)])
+        outs = reps2(c, g, m)
+        assert all(math.isfinite(o["loss"]) for o in outs)
+    assert reps2.steps[1].recaptures >= 1
+    for r in (0, 2):
+        assert dist(solos[r][0], models2[r]) <= max(4.0 * noise, 1e-5), r
+    assert dist(solos[1][0], models2[1]) <= 5e-3
+
+
 def _silhouettes(cams, models_v_f_params, bg):
     """garment silhouettes of the cameras: the initial model's own alpha > 0.05, as a segmentation mask would be"""
     from ggsplat.inner_step import DEFAULT_PIPE

@@ -62,6 +62,12 @@ import json,sys; d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_
     ldspad)          # occupancy cap of the per-quadrant kernels through unused dynamic LDS (GGS_QUAD_LDS_PAD): forward time + graph step
       for pad in ${PADS:-0 8192 14336 17408 24576 36864}; do echo -n "GGS_QUAD_LDS_PAD=$pad "; GGS_QUAD_LDS_PAD=$pad timeout 200 python tools/dbg/time_fwd.py 1 20 2>&1 | tail -1
         echo -n "GGS_QUAD_LDS_PAD=$pad "; GGS_QUAD_LDS_PAD=$pad timeout 300 python tools/profile_graph_step.py 256 2>&1 | tail -1; done > $OUT/${TAG}_ldspad.txt 2>&1; cat $OUT/${TAG}_ldspad.txt ;;
+    replicas)        # replica mode (R independent s2 registrations on R streams): aggregate rates, then the kernel overlap of R = 4 under the tracer
+      { echo "## aggregate rates (unprofiled): python tools/dbg/replica_rate.py 128"; echo; timeout 600 python tools/dbg/replica_rate.py 128 2>&1 | grep -v amdgpu.ids; echo;
+        R=$PWD; for rr in ${REPLICAS:-1 4}; do (cd /tmp && timeout 400 rocprofv3 --kernel-trace -d $R/$OUT/rep$rr -o p -- python $R/tools/dbg/replica_rate.py 48 --trace $rr > $R/$OUT/rep$rr.log 2>&1)
+          echo "## R = $rr under rocprofv3 --kernel-trace (last ${LAST_MS:-30} ms of the trace)"; echo; python tools/overlap_summary.py $(find $OUT/rep$rr -name "*.db" | head -1) --last-ms ${LAST_MS:-30}; echo; grep "^R = " $OUT/rep$rr.log; echo; rm -rf $OUT/rep$rr; done; } > $OUT/${TAG}_replicas.md 2>&1; cat $OUT/${TAG}_replicas.md ;;
+    stampstep)       # per-kernel microseconds of the captured s2 iteration from timestamps captured inside the graph (no profiler)
+      for f in $( [ -z "$LIBS" ] && echo gaussian-garments_amd/csrc/libggsplat.so || libs ); do GGS_LIB_PATH=$PWD/$f timeout 300 python tools/dbg/stamp_graph_step.py ${N:-64} 2>&1 | grep -v amdgpu.ids | tail -3; done > $OUT/${TAG}_stampstep.txt; cat $OUT/${TAG}_stampstep.txt ;;
     knn)             timeout 300 python tools/dbg/time_knn.py > $OUT/${TAG}_knn.txt 2>&1; tail -2 $OUT/${TAG}_knn.txt ;;
     bench)           timeout 900 python bench.py $BENCH_ARGS > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err; cat $OUT/${TAG}_bench.json ;;
     *) echo "unknown step $step" ;;
