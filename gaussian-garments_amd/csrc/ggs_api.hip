@@ -209,7 +209,9 @@ int ggs_workspace_sizes(const GgsParams* p, size_t bin_capacity, size_t* geom_by
     if (geom_bytes) *geom_bytes = ggs_align(V * (size_t)p->P * sizeof(SplatRec)) + ggs_align(V * (size_t)p->P * sizeof(SplatAux));
     const BinLayout L = ggs_bin_layout(p->n_views, d.T, bin_capacity);
     // img: final_T | n_contrib
-    if (img_bytes) *img_bytes = ggs_align(V * (size_t)p->W * p->H * 4) * 2;
+    // + the checkpoints of the segmented backward when this shape runs the latency mapping (ggs_common.h GGS_SEG)
+    if (img_bytes) *img_bytes = ggs_align(V * (size_t)p->W * p->H * 4) * 2 +
+                                ((long long)V * d.T < (long long)GGS_QUAD_ITEMS ? ggs_align(ggs_ckpt_bytes(bin_capacity)) : 0);
     if (bin_bytes) *bin_bytes = L.total;
     return GGS_OK;
 }
@@ -497,6 +499,8 @@ int forward_impl(int phases, const GgsParams* p, const float* bg, const float* m
         a.n_items = n_items; a.order = order; a.tile_count = tile_count; a.tile_offset = tile_offset; a.view_base = view_base; a.ids = ids;
         a.rec = (const SplatRec*)geom; a.bg = bg; a.out_color = out_color; a.out_depth = out_depth;
         a.out_alpha = out_alpha; a.final_T = final_T; a.n_contrib = n_contrib;
+        a.ckpt = n_items < GGS_QUAD_ITEMS ? (float*)((char*)img + 2 * ggs_align((size_t)V * HW * 4)) : nullptr;
+        a.ckpt_slots = (unsigned)ggs_ckpt_slots(bin_capacity);
         prof_start(K_RENDER_FWD, s);
         if (n_items < GGS_QUAD_ITEMS) hipLaunchKernelGGL(ggs_k_render_fwd_quad, dim3((unsigned)n_items * GGS_NQ), dim3(64), 0, s, a);
         else hipLaunchKernelGGL(ggs_k_render_fwd, dim3((unsigned)n_items), dim3(64), 0, s, a);
@@ -587,13 +591,14 @@ int ggs_backward(const GgsParams* p, const float* bg, const float* means3D, cons
         a.dL_dcolor = dL_dcolor; a.dL_ddepth = dL_ddepth; a.dL_dalpha = dL_dalpha;
         a.acc = (GradRec*)scratch;
         a.header = (const GgsBinHeader*)(b + L.header);
+        a.ckpt = a.n_items < GGS_QUAD_ITEMS ? (const float*)((const char*)img + 2 * ggs_align((size_t)V * HW * 4)) : nullptr;
+        a.ckpt_slots = (unsigned)ggs_ckpt_slots(bin_capacity);
         const dim3 gridT((unsigned)(V * d.T));   // one wave64 per (view, tile) work item, longest lists first
         prof_start(K_RENDER_BWD, s);
         const bool da = dL_ddepth || dL_dalpha;
-        if (a.n_items < GGS_QUAD_ITEMS) {
-            const dim3 gridQ((unsigned)(a.n_items * GGS_NQ));
-            if (da) hipLaunchKernelGGL(ggs_k_render_bwd_da_quad, gridQ, dim3(64), 0, s, a);
-            else hipLaunchKernelGGL(ggs_k_render_bwd_quad, gridQ, dim3(64), 0, s, a);
+        if (a.n_items < GGS_QUAD_ITEMS && da) {      // latency mapping with depth / alpha gradients: unsegmented per-quadrant walks
+            a.ckpt = nullptr;
+            hipLaunchKernelGGL(ggs_k_render_bwd_da_quad, dim3((unsigned)(a.n_items * GGS_NQ)), dim3(64), 0, s, a);
         } else if (da) hipLaunchKernelGGL(ggs_k_render_bwd_da, gridT, dim3(64), 0, s, a);
         else hipLaunchKernelGGL(ggs_k_render_bwd, gridT, dim3(64), 0, s, a);
         prof_stop(K_RENDER_BWD, s);

@@ -93,6 +93,24 @@ struct GradRec {                 // per-(view, Gaussian) accumulators over the p
 };
 static_assert(sizeof(GradRec) == 48, "GradRec must be 48 bytes");
 
+// Segmented backward of the latency mapping (round 6).  A single view does not fill the chip, and its backward used to be as long
+// as the walks of its longest lists (~1000 entries).  The REVERSE walk can be cut exactly where the forward left a checkpoint: at
+// list position b the backward needs, per pixel, the transmittance in front of entry b (the forward's own T at that point) and
+//   B_b = T_final (bg . dL/dC) + sum_{k >= b} w_k (c_k . dL/dC)  =  T_final (bg . dL/dC) + (C_final - C_b) . dL/dC
+// -- the colour the forward had accumulated at b against the colour it ended with.  The per-quadrant forward stores {T, C0, C1, C2} of
+// its 64 pixels in front of every round (list positions that are multiples of GGS_SEG = 64), and its final accumulators once per
+// tile with more than GGS_SEG entries; the backward then runs one wave per (tile, segment of GGS_SEG positions), all independent:
+// ~5 000 walks of <= 64 entries instead of ~1 100 walks of up to ~1 000.  (Gradients of the depth / alpha outputs -- no loss of the
+// reference has them -- would need D and A in the records too: that backward keeps the unsegmented per-quadrant walk.)
+//   slot of the checkpoint at list position b of a tile whose list starts at global entry `base`:  (base + b) / GGS_SEG
+//   slot of the tile's final record:  n_slots + base / GGS_SEG        (both collision-free: lists do not overlap)
+//   record layout [slot][GGS_NQ][GGS_CKPT_PLANES][64] floats, behind final_T | n_contrib in the img workspace (latency mapping only).
+#define GGS_SEG 64
+#define GGS_CKPT_PLANES 4
+#define GGS_MAX_SEG 24           // segments per list; the last scheduled one takes everything behind it
+static inline size_t ggs_ckpt_slots(size_t cap) { return cap / GGS_SEG + 2; }
+static inline size_t ggs_ckpt_bytes(size_t cap) { return 2 * ggs_ckpt_slots(cap) * (size_t)GGS_NQ * GGS_CKPT_PLANES * 64 * 4; }
+
 struct BinLayout {               // byte offsets inside the binning buffer
     size_t header, tile_count, tile_cursor, tile_offset, view_base, order, keys, ids, total;
     size_t zero_bytes;           // header + tile_count + tile_cursor are cleared each forward
@@ -157,6 +175,39 @@ __device__ __forceinline__ NonEmptyItems ggs_nonempty_items(const uint32_t* buck
     it.stride = (it.n ? (E / it.n) & ~1u : 0) + 1;
     it.n_long = bucket_count[0] + bucket_count[1] + bucket_count[2] + bucket_count[3];
     return it;
+}
+
+// Which (list, segment) a block of the segmented backward walks.  Ranks below it.n are segment 0 of the non-empty work items,
+// as ever.  Segment k >= 1 (list positions >= k GGS_SEG) exists for the lists longer than k GGS_SEG; order[] holds the lists by
+// length CLASS, longest first, so "the lists of at least lenlo[c] entries" are exactly the first cum[c] ranks, and segment k is
+// given to the first m_k = cum[c(k)] ranks, c(k) the class with the largest lower bound <= k GGS_SEG (a superset of the lists that
+// have the segment: the few blocks too many return at once).  The later segments ride on the blocks of EMPTY tiles, which have
+// nothing to do: spare rank e = rank - it.n takes the (e - offset_k)-th list of segment k, offset_k = m_1 + ... + m_(k-1).  When the
+// spare ranks do not reach all segments, the last one that fits (k = n_extra) is open-ended for every list: correct for any count,
+// and every block computes the same numbers from the bin header.
+struct SegItem { uint32_t rank; int seg, n_extra; bool valid; };
+__device__ __forceinline__ SegItem ggs_seg_item(const uint32_t* bucket_count, const NonEmptyItems& it, uint32_t n_items, uint32_t rank) {
+    SegItem r;
+    r.rank = rank; r.seg = 0; r.n_extra = 0; r.valid = rank < it.n;
+    // lower bounds of the list-length classes 0..11 (ggs_len_bucket) and their cumulative counts
+    const int lenlo[12] = {3072, 2048, 1536, 1024, 768, 512, 384, 256, 192, 128, 96, 64};
+    uint32_t cum[12], run = 0;
+#pragma unroll
+    for (int c = 0; c < 12; ++c) { run += bucket_count[c]; cum[c] = run; }
+    const uint32_t n_spare = n_items - it.n;
+    uint32_t offset = 0;
+    const uint32_t e = rank - it.n;            // (meaningful for spare ranks only)
+    int c = 11;
+    for (int k = 1; k < GGS_MAX_SEG; ++k) {
+        while (c > 0 && lenlo[c - 1] <= k * GGS_SEG) --c;      // class with the largest lower bound <= k GGS_SEG
+        const uint32_t m = cum[c];
+        if (m == 0 || offset + m > n_spare) break;
+        r.n_extra = k;
+        if (rank >= it.n && e >= offset && e < offset + m) { r.rank = e - offset; r.seg = k; r.valid = true; }
+        offset += m;
+    }
+    if (r.seg > r.n_extra) r.valid = false;
+    return r;
 }
 
 // Tile rectangle of a splat (A.1 step 6) in the REFERENCE's 16x16 tiles (gx = ceil(W / 16) columns); must be bit-identical

@@ -74,6 +74,8 @@ struct RenderArgs {
     float* out_alpha;         // [V][H][W]
     float* final_T;           // [V][H][W]
     uint32_t* n_contrib;      // [V][H][W]
+    float* ckpt;              // latency mapping: checkpoints for the segmented backward (ggs_common.h GGS_SEG), else null
+    unsigned ckpt_slots;
 };
 
 struct RenderBwdArgs {
@@ -94,6 +96,8 @@ struct RenderBwdArgs {
     const float* dL_dalpha;   // [V][H][W] or null
     GradRec* acc;             // [V][P]
     const GgsBinHeader* header;   // overflow != 0: the forward did not composite -> the backward does nothing
+    const float* ckpt;        // latency mapping: the forward's checkpoints (null: unsegmented walk)
+    unsigned ckpt_slots;
 };
 
 struct PreBwdArgs {
@@ -120,7 +124,6 @@ __global__ void ggs_k_render_fwd(RenderArgs a);
 __global__ void ggs_k_render_fwd_quad(RenderArgs a);
 __global__ void ggs_k_render_bwd(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_da(RenderBwdArgs a);
-__global__ void ggs_k_render_bwd_quad(RenderBwdArgs a);
 __global__ void ggs_k_render_bwd_da_quad(RenderBwdArgs a);
 __global__ void ggs_k_count_blends(RenderBwdArgs a, unsigned long long* out, int n_out);
 __global__ void ggs_k_count_forward_visits(RenderArgs a, unsigned long long* out);

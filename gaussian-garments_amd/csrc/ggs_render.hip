@@ -250,6 +250,14 @@ __device__ __forceinline__ PairAlpha test_pair(const PairRec& r, float pxf, floa
     return p;
 }
 
+// Checkpoint record of one (slot, quadrant): GGS_CKPT_PLANES planes of 64 floats (ggs_common.h GGS_SEG).
+__device__ __forceinline__ float* ckpt_record(float* ckpt, size_t slot, int q0, int lane) {
+    return ckpt + ((slot * GGS_NQ + (size_t)q0) * GGS_CKPT_PLANES) * 64 + lane;
+}
+__device__ __forceinline__ void ckpt_store(float* rec, float T, float C0, float C1, float C2) {
+    rec[0] = T; rec[64] = C0; rec[128] = C1; rec[192] = C2;
+}
+
 // K4b body, latency mapping (one wave per (tile, quadrant), launches too small to fill the chip).  The kernel is as long as its
 // dozen longest walks (profiles/r05_wave_timeline.md), and those run on SIMDs they have to themselves.  What a lone wave pays
 // for is the NUMBER of instructions it issues -- ~6-9 cycles per VALU instruction whether or not it depends on the one before
@@ -295,6 +303,11 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
         Rec3 nxt = gather_round(rec, ids, 0, L, lane);
         uint32_t w_ahead = gather_ids(ids, 64, L, lane);
         for (int first = 0; first < L && dead != ~0ull; first += 64) {
+            // segmented backward: the state in front of list position `first`, i.e. of every round but the first (a wave that finished all
+            // its pixels earlier never gets here: then no pixel's last contributor lies behind, and nobody reads the record)
+            static_assert(GGS_SEG == 64, "one checkpoint in front of every round");
+            if (a.ckpt && first)
+                ckpt_store(ckpt_record(a.ckpt, (base + (size_t)first) / GGS_SEG, q0, lane), T, C0, C1, C2);
             const Rec3 cur = nxt;
             if (first + 64 < L) { nxt = gather_recs(rec, w_ahead); w_ahead = gather_ids(ids, first + 128, L, lane); }
             const int n = min(64, L - first);
@@ -392,6 +405,8 @@ __device__ __forceinline__ void render_fwd_quadwave(const RenderArgs& a) {
             if (dead == ~0ull) break;
         }
     }
+    // ... and what the accumulators ended with, once per tile whose list has more than one segment
+    if (a.ckpt && L > GGS_SEG) ckpt_store(ckpt_record(a.ckpt, (size_t)a.ckpt_slots + base / GGS_SEG, q0, lane), T, C0, C1, C2);
     if (!inside) return;
     const size_t HW = (size_t)a.H * a.W;
     const float* bg = a.bg + 3 * v;
@@ -426,13 +441,22 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
     // tiles of a view have nothing to differentiate, and their waves -- which used to be interleaved with the real ones for
     // the forward's sake -- exit on one scalar compare behind all the work instead of in front of it.
     const NonEmptyItems it = ggs_nonempty_items(a.bucket_count, (uint32_t)a.n_items);
-    const uint32_t rank = NQ == GGS_NQ ? blockIdx.x : blockIdx.x / GGS_NQ;
-    if (rank >= it.n) return;
+    uint32_t rank = NQ == GGS_NQ ? blockIdx.x : blockIdx.x / GGS_NQ;
+    // Latency mapping, SEGMENTED (ggs_common.h GGS_SEG, ggs_seg_item): with the forward's checkpoints at hand the walk of a list is
+    // cut into segments of GGS_SEG positions, one wave each; the later segments ride on the blocks of the empty tiles.
+    int seg = 0, n_extra = 0;
+    if (a.ckpt) {
+        const SegItem si = ggs_seg_item(a.bucket_count, it, (uint32_t)a.n_items, rank);
+        if (!si.valid) return;
+        rank = si.rank; seg = si.seg; n_extra = si.n_extra;
+    } else if (rank >= it.n) return;
     const uint32_t item = a.order[(size_t)rank * it.stride];
     const int q0 = NQ == GGS_NQ ? 0 : (int)(blockIdx.x % GGS_NQ);            // NQ = 1: one wave per sub-block
     const int v = (int)(item / (uint32_t)a.T), t = (int)(item % (uint32_t)a.T), lane = threadIdx.x;
     const int L = (int)a.tile_count[(size_t)v * a.T + t];
-    if (L == 0) return;
+    const int lo = seg * GGS_SEG;                                            // this wave walks the list positions [lo, hi)
+    const int hi = seg == n_extra ? 0x7fffffff : lo + GGS_SEG;
+    if (L <= lo) return;
     const int tx = t % a.gx, ty = t / a.gx;
     const int ox = tx * GGS_TILE_W, oy = ty * GGS_TILE;
     const int px0 = ox + (lane & 7), py0 = oy + (lane >> 3);
@@ -463,7 +487,6 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
         const size_t pix = (size_t)py * a.W + px;
         pxf[q] = (float)px; pyf[q] = (float)py;
         nc[q] = inside ? (int)a.n_contrib[(size_t)v * HW + pix] : 0;
-        maxc = max(maxc, nc[q]);
         T[q] = inside ? a.final_T[(size_t)v * HW + pix] : 1.f;
         dC0[q] = dC1[q] = dC2[q] = 0.f; dD[q] = dA[q] = 0.f;
         if (inside) {
@@ -475,6 +498,21 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
             }
         }
         B[q] = T[q] * (bg0 * dC0[q] + bg1 * dC1[q] + bg2 * dC2[q]);
+        if (a.ckpt) {
+            // A pixel whose last contributor lies BEHIND this segment starts from the forward's checkpoint at `hi`: the
+            // transmittance in front of entry hi, and B = T_final (bg . dL/dC) + (what the forward accumulated from hi on) . dL/dC.
+            // One whose last contributor lies inside starts as the unsegmented walk does; one that ends in front has nothing here.
+            if (nc[q] > hi) {
+                const float* ck = ckpt_record(const_cast<float*>(a.ckpt), (base + (size_t)hi) / GGS_SEG, q0 + q, lane);
+                const float* fin = ckpt_record(const_cast<float*>(a.ckpt), (size_t)a.ckpt_slots + base / GGS_SEG, q0 + q, lane);
+                static_assert(GGS_CKPT_PLANES == 4, "T, C0, C1, C2: the depth / alpha backward is never segmented (ggs_backward)");
+                T[q] = ck[0];
+                B[q] += (fin[64] - ck[64]) * dC0[q] + (fin[128] - ck[128]) * dC1[q] + (fin[192] - ck[192]) * dC2[q];
+                nc[q] = hi;
+            }
+            if (nc[q] <= lo) nc[q] = 0;
+        }
+        maxc = max(maxc, nc[q]);
     }
     // GradRec field this lane adds to after the reduction (lds_transpose_reduce leaves total v in lane 8 v, the ninth in lane 63)
     const int fld = lds_reduce_field<DA>(lane);
@@ -496,18 +534,19 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
     if (lane < 8) reinterpret_cast<float*>(s_zero)[lane] = 0.f;
     __builtin_amdgcn_wave_barrier();
     const int fld_bytes = fld * 4;
-    // rounds of 64 list positions, walked from the back: round r covers [64 r, 64 r + 64)
+    // rounds of 64 list positions, walked from the back: round r covers [64 r, 64 r + 64); a segment ends at round lo / 64
     int r = (maxc - 1) >> 6;
+    const int r_lo = lo >> 6;
     Rec3 nxt = gather_round(rec, ids, r * 64, L, lane);
     // Latency mapping: id words two rounds ahead, records one round ahead, as in render_fwd_quadwave -- a lone wave otherwise sits
     // out the id load of every round before it can even ask for the records (the tile waves have other waves to run meanwhile).
     uint32_t w_ahead = 0;
-    if (NQ == 1 && r > 0) w_ahead = gather_ids(ids, (r - 1) * 64, L, lane);
-    for (; r >= 0; --r) {
+    if (NQ == 1 && r > r_lo) w_ahead = gather_ids(ids, (r - 1) * 64, L, lane);
+    for (; r >= r_lo; --r) {
         const Rec3 cur = nxt;
         if (NQ == 1) {
-            if (r > 0) { nxt = gather_recs(rec, w_ahead); if (r > 1) w_ahead = gather_ids(ids, (r - 2) * 64, L, lane); }
-        } else if (r > 0) nxt = gather_round(rec, ids, (r - 1) * 64, L, lane);
+            if (r > r_lo) { nxt = gather_recs(rec, w_ahead); if (r > r_lo + 1) w_ahead = gather_ids(ids, (r - 2) * 64, L, lane); }
+        } else if (r > r_lo) nxt = gather_round(rec, ids, (r - 1) * 64, L, lane);
         const int first = r * 64;
         const int n = min(64, maxc - first);
         // Entries of the round the forward blended somewhere in this wave's pixels, as a lane mask (lane i holds entry i):
@@ -664,7 +703,9 @@ __device__ __forceinline__ void render_bwd_body(const RenderBwdArgs& a) {
 // (no loss on depth / alpha: s2_registration.py:258-267, s3_appearance.py:131-140) carries no dead work.
 __global__ __launch_bounds__(64) void ggs_k_render_bwd(RenderBwdArgs a) { render_bwd_body<false, GGS_NQ>(a); }
 __global__ __launch_bounds__(64) void ggs_k_render_bwd_da(RenderBwdArgs a) { render_bwd_body<true, GGS_NQ>(a); }
-__global__ __launch_bounds__(64) void ggs_k_render_bwd_quad(RenderBwdArgs a) { render_bwd_body<false, 1>(a); }
+// Latency mapping of the backward (launches too small to fill the chip).  Without depth / alpha gradients: ggs_k_render_bwd with the
+// forward's checkpoints (a.ckpt) -- one tile wave per SEGMENT of 64 list positions.  With them (no loss of the reference): the
+// unsegmented per-quadrant walk, two entries per iteration.
 __global__ __launch_bounds__(64) void ggs_k_render_bwd_da_quad(RenderBwdArgs a) { render_bwd_body<true, 1>(a); }
 
 // Introspection (bench.py's compute-side roofline): the number of (splat, pixel) pairs the forward BLENDED, i.e. the pairs

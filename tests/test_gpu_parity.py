@@ -114,6 +114,54 @@ def test_no_depth_alpha_grads_kernel():
     _compare(sc, cam, (0.0, 0.0, 0.0), dict(sh=True, cov=False, da=False))
 
 
+def _segments_scheduled(sc, cam, dev="cuda"):
+    """How the segmented backward cuts this view's lists: (lists of >= 64 entries, longest list, n_extra) -- ggs_seg_item of
+    csrc/ggs_common.h replayed on the forward's bin header."""
+    from ggsplat import rasterizer as R
+    from ggsplat.synthetic import stack_cameras
+    cams = stack_cameras([cam], device=dev)
+    *_, st = R.forward_views(sc["means3D"].to(dev), sc["opacities"].to(dev), None, sc["colors"].to(dev), sc["scales"].to(dev),
+                             sc["rotations"].to(dev), None, view=cams["view"], proj=cams["proj"], campos=cams["campos"],
+                             tanfov=cams["tanfov"], bg=torch.zeros(3, device=dev), W=cam.image_width, H=cam.image_height, sh_degree=0)
+    counts = R.bin_sections(st)["tile_count"].cpu().numpy().reshape(-1)
+    bucket = st.bin[64:128].view(torch.int32).cpu().numpy().astype(np.int64)
+    T = counts.size
+    n_ne = int((counts > 0).sum())
+    assert int(bucket[15]) == T - n_ne
+    lenlo = [3072, 2048, 1536, 1024, 768, 512, 384, 256, 192, 128, 96, 64]
+    cum = np.cumsum(bucket[:12])
+    n_extra, offset, c = 0, 0, 11
+    for k in range(1, 24):
+        while c > 0 and lenlo[c - 1] <= k * 64:
+            c -= 1
+        if cum[c] == 0 or offset + cum[c] > T - n_ne:
+            break
+        n_extra, offset = k, offset + int(cum[c])
+    return int(cum[11]), int(counts.max()), n_extra
+
+
+@pytest.mark.parametrize("P,spread,W,H,regime", [(1000, 0.12, 320, 256, "all"), (2000, 0.30, 128, 96, "truncated"), (2600, 1.0, 64, 48, "none")])
+def test_segmented_backward_in_all_scheduling_regimes(P, spread, W, H, regime):
+    """The latency-mapped backward without depth / alpha gradients walks SEGMENTS of 64 list positions from the forward's
+    checkpoints (csrc/ggs_common.h GGS_SEG); the later segments ride on the blocks of empty tiles.  Three regimes against the
+    C oracle, every gradient <= 1e-4: a cluster in a mostly empty image (every segment of every list has its own wave), fewer
+    spare blocks than segments (the last scheduled segment is open-ended), and an image without empty tiles (one wave per list)."""
+    sc, cam = small_scene(P=P, W=W, H=H, sh_degree=0, seed=17, scale_mul=2.0)
+    sc["means3D"] = sc["means3D"] * spread                       # a cluster around the look-at point: long lists on few tiles
+    sc = _add_precomp(sc)
+    n_long, longest, n_extra = _segments_scheduled(sc, cam)
+    needed = (longest - 1) // 64
+    assert longest > 192, longest
+    if regime == "all":
+        assert n_extra >= needed >= 3, (n_extra, needed)
+    elif regime == "truncated":
+        assert 1 <= n_extra < needed, (n_extra, needed)
+    else:
+        assert n_extra == 0 and n_long > 0
+    for bg in ((0.0, 0.0, 0.0), (0.3, 0.6, 0.1)):
+        _compare(sc, cam, bg, dict(sh=False, cov=False, da=False))
+
+
 def test_scale_modifier():
     sc, cam = small_scene(P=400, W=64, H=48, sh_degree=0, seed=23, scale_mul=5.0)
     _compare(sc, cam, (1.0, 1.0, 1.0), dict(sh=True, cov=False), scale_modifier=0.7)
