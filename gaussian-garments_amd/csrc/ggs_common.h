@@ -76,11 +76,12 @@ static_assert(sizeof(SplatRec) == 48, "SplatRec must be 48 bytes");
 struct SplatAux {
     int radius;                  // 3-sigma radius in px (the `radii` output); 0 = culled
     unsigned clamped;            // bit c set: SH colour channel c was clamped at 0
-    unsigned long long tile_bits;  // bit (ry * rect_w + rx): tile (x0 + rx, y0 + ry) of the culled rect is reachable;
-                                   // valid when the rect has <= 64 tiles (GGS_TILE_BITS_MAX), else recomputed
+    unsigned long long tile_bits;  // GGS_NQ bits per tile of the culled rect, row-major (tile index ry * rect_w + rx): the sub-blocks of
+                                   // tile (x0 + rx, y0 + ry) the splat can be blended in (ggs_quad_bits; 0 = not on that tile's list);
+                                   // valid when the rect has <= GGS_TILE_BITS_MAX tiles, else recomputed by the scatter pass
 };
 static_assert(sizeof(SplatAux) == 16, "SplatAux must be 16 bytes");
-#define GGS_TILE_BITS_MAX 64
+#define GGS_TILE_BITS_MAX (64 / GGS_NQ)      // tiles of a culled rect whose GGS_NQ-bit sub-block masks fit SplatAux.tile_bits
 
 struct GradRec {                 // per-(view, Gaussian) accumulators over the pixels that blended the splat,
                                  // with t = G dL/dalpha and d = mean - pixel:
@@ -271,61 +272,57 @@ __device__ __forceinline__ Footprint ggs_footprint(float px, float py, float qa,
     return f;
 }
 
-__device__ __forceinline__ float ggs_edge_min_x(const Footprint& f, float xe, float y0, float y1) {   // x fixed
-    const float dx = xe - f.mx;
-    const float dy = ggs_min(y1 - f.my, ggs_max(y0 - f.my, -f.BoC * dx));   // clamped 1-D minimiser
-    return f.A * dx * dx + 2.f * f.B * dx * dy + f.C * dy * dy;
-}
-__device__ __forceinline__ float ggs_edge_min_y(const Footprint& f, float ye, float x0, float x1) {   // y fixed
-    const float dy = ye - f.my;
-    const float dx = ggs_min(x1 - f.mx, ggs_max(x0 - f.mx, -f.BoA * dy));
-    return f.A * dx * dx + 2.f * f.B * dx * dy + f.C * dy * dy;
-}
-// Only the edges FACING the mean can hold the minimum: from any point of the box the segment to the mean
-// decreases q and leaves the box through one of them.
-// Branch-free: ONE vertical and ONE horizontal edge are always evaluated -- the facing one where there is one, else
-// an arbitrary one, whose minimum is the value at a box point and therefore >= the box minimum (harmless in the min).
-// Neighbouring lanes sit in different regions around the splat, so the branchy form executed all four edge blocks.
-__device__ __forceinline__ bool ggs_box_reachable(const Footprint& f, float x0, float y0, float x1, float y1) {
-    const bool left = f.mx < x0, right = f.mx > x1, above = f.my < y0, below = f.my > y1;
-    const float qv = ggs_edge_min_x(f, right ? x1 : x0, y0, y1);
-    const float qh = ggs_edge_min_y(f, below ? y1 : y0, x0, x1);
-    const bool inside = !(left | right | above | below);                 // mean inside the box: q = 0 there
-    return inside ? f.lim > 0.f : ggs_min(qv, qh) <= f.lim;
-}
+// Only the edges FACING the mean can hold the minimum: from any point of the box the segment to the mean decreases q and leaves
+// the box through one of them.  Branch-free: ONE vertical and ONE horizontal edge are always evaluated -- the facing one where there
+// is one, else an arbitrary one, whose minimum is the value at a box point and therefore >= the box minimum (harmless in the min).
 
-// Which 8x8 sub-blocks of tile (tx, ty) the splat can be blended in, positioned at the top GGS_NQ bits of the id word;
-// 0 = the tile can be dropped from the splat's list (output-invariant).  The AABB pre-test is integer work.
-// c0, c1: the splat's (culled) reference rectangle in 16-pixel columns [c0, c1): with tiles wider than 16 pixels the
-// reference still cuts the splat at ITS tile columns, so sub-blocks outside them must stay clear.
-__device__ __forceinline__ unsigned long long ggs_quad_mask(const Footprint& f, unsigned bbx, unsigned bby, int tx,
-                                                            int ty, int c0, int c1) {
+// Which 8x8 sub-blocks of tile (tx, ty) the splat can be blended in: bit q set = sub-block q (x in [8 (q % GGS_QX), +8), y in
+// [8 (q / GGS_QX), +8) of the tile) is reachable.  0 = the tile is NOT on the splat's list (output-invariant: no pixel centre of the
+// tile can reach alpha >= 1/255) -- list membership and quadrant mask are ONE decision since round 6 (the histogram pass computes
+// it once per (splat, tile) and leaves it in SplatAux.tile_bits; the scatter pass reads it back).
+// The test per sub-block is ggs_box_reachable's: the minimum of q over the box sits on an edge facing the mean, a clamped 1-D
+// parabola.  On the regular 8-pixel grid of a tile the per-COLUMN terms of the vertical-edge parabolas (dx, A dx^2, 2 B dx, the
+// unclamped minimiser -B/C dx) and the per-ROW terms of the horizontal ones are shared by the sub-blocks of that column / row:
+// they are formed once per tile, and a sub-block costs two clamps (v_med3) and four fused multiply-adds.
+// c0, c1: the splat's (culled) reference rectangle in 16-pixel columns [c0, c1): with tiles wider than 16 pixels the reference
+// still cuts the splat at ITS tile columns, so sub-blocks outside them stay clear.
+__device__ __forceinline__ float ggs_med3(float a, float lo, float hi) { return __builtin_amdgcn_fmed3f(a, lo, hi); }
+__device__ __forceinline__ unsigned ggs_quad_bits(const Footprint& f, unsigned bbx, unsigned bby, int tx, int ty, int c0, int c1) {
     const int xmin = ggs_bb_min(bbx), xmax = ggs_bb_max(bbx), ymin = ggs_bb_min(bby), ymax = ggs_bb_max(bby);
     const int ox = tx * GGS_TILE_W, oy = ty * GGS_TILE;
-    const float fx = (float)ox, fy = (float)oy;
-    unsigned m = 0, aabb = 0;
+    // per column of sub-blocks: the x interval relative to the mean, the vertical edge facing the mean and its parabola terms
+    float xl[GGS_QX], xh[GGS_QX], vA[GGS_QX], vB[GGS_QX], vT[GGS_QX];
+    bool inx[GGS_QX], colok[GGS_QX];
 #pragma unroll
-    for (int q = 0; q < GGS_NQ; ++q) {
-        const int bx = ox + 8 * (q % GGS_QX), by = oy + 8 * (q / GGS_QX);
-        const bool col = GGS_TS == 1 || ((bx >> 4) >= c0 && (bx >> 4) < c1);
-        const bool hit = col && xmin <= bx + 7 && xmax >= bx && ymin <= by + 7 && ymax >= by;
-        if (hit) aabb |= 1u << q;
-        if (hit && ggs_box_reachable(f, (float)bx, (float)by, (float)bx + 7.f, (float)by + 7.f)) m |= 1u << q;
+    for (int cx = 0; cx < GGS_QX; ++cx) {
+        const int bx = ox + 8 * cx;
+        xl[cx] = (float)bx - f.mx; xh[cx] = (float)(bx + 7) - f.mx;
+        inx[cx] = xl[cx] <= 0.f && xh[cx] >= 0.f;
+        const float dx = xh[cx] < 0.f ? xh[cx] : xl[cx];                 // mean right of the box: its right edge, else the left one
+        vA[cx] = f.A * dx * dx; vB[cx] = 2.f * f.B * dx; vT[cx] = -f.BoC * dx;
+        colok[cx] = (GGS_TS == 1 || ((bx >> 4) >= c0 && (bx >> 4) < c1)) && xmin <= bx + 7 && xmax >= bx;
     }
-    (void)fx; (void)fy;
-    // The LIST MEMBERSHIP of the tile is decided by ggs_tile_reachable alone (used identically by the histogram
-    // and the scatter).  If rounding makes all sub-block tests fail on a tile that passed, keep the AABB mask.
-    if (!m) m = aabb;
-    return (unsigned long long)m << GGS_ID_BITS;
-}
-
-// Can the splat be blended anywhere in tile (tx, ty)?  (the tile is already inside the culled rectangle; c0, c1 as above:
-// only the tile's 16-pixel columns inside [c0, c1) count)
-__device__ __forceinline__ bool ggs_tile_reachable(const Footprint& f, int tx, int ty, int c0, int c1) {
-    int bx0 = tx * GGS_TILE_W, bx1 = bx0 + GGS_TILE_W - 1;
-    if (GGS_TS > 1) { bx0 = bx0 > c0 * 16 ? bx0 : c0 * 16; bx1 = bx1 < c1 * 16 - 1 ? bx1 : c1 * 16 - 1; }
-    const float fy = (float)(ty * GGS_TILE);
-    return ggs_box_reachable(f, (float)bx0, fy, (float)bx1, fy + 15.f);
+    unsigned m = 0;
+#pragma unroll
+    for (int cy = 0; cy < 2; ++cy) {
+        const int by = oy + 8 * cy;
+        const float yl = (float)by - f.my, yh = (float)(by + 7) - f.my;
+        const bool iny = yl <= 0.f && yh >= 0.f;
+        const float dy = yh < 0.f ? yh : yl;                             // mean below the box: its bottom edge, else the top one
+        const float hC = f.C * dy * dy, hB = 2.f * f.B * dy, hT = -f.BoA * dy;
+        const bool rowok = ymin <= by + 7 && ymax >= by;
+#pragma unroll
+        for (int cx = 0; cx < GGS_QX; ++cx) {
+            // vertical edge: x fixed, y clamped to the box; horizontal edge: y fixed, x clamped
+            const float ey = ggs_med3(vT[cx], yl, yh);
+            const float qv = fmaf(ey, fmaf(f.C, ey, vB[cx]), vA[cx]);
+            const float ex = ggs_med3(hT, xl[cx], xh[cx]);
+            const float qh = fmaf(ex, fmaf(f.A, ex, hB), hC);
+            const bool reach = (inx[cx] && iny) ? f.lim > 0.f : ggs_min(qv, qh) <= f.lim;
+            if (rowok && colok[cx] && reach) m |= 1u << (cy * GGS_QX + cx);
+        }
+    }
+    return m;
 }
 
 // [x0, x1) in the reference's 16-pixel columns -> tile columns [X0, X1)

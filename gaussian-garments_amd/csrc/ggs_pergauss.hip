@@ -174,8 +174,9 @@ __device__ __forceinline__ void preprocess_body(const PreArgs& a) {
     const Footprint fp = ggs_footprint(out.px, out.py, out.cx, out.cy, out.cz, out.opacity);
     uint32_t* cnt = a.tile_count + (size_t)v * a.T;
     const TileWindow w = block_tile_window(s_box, has, x0, y0, x1, y1);
-    // The exact ellipse-vs-tile test runs ONCE per (splat, tile): its outcome is kept as a bitmask over the culled
-    // rect (row-major, <= 64 tiles) in SplatAux so the scatter kernel's two passes only test a bit.
+    // The exact ellipse-vs-sub-block tests run ONCE per (splat, tile): list membership (any sub-block reachable) and the quadrant
+    // mask are one result, kept GGS_NQ bits per tile of the culled rect (row-major, <= GGS_TILE_BITS_MAX tiles) in SplatAux so the
+    // scatter kernel's passes only read bits (round 6: it used to repeat four box tests per member, 160 VALU instructions).
     unsigned long long bits = 0;
     unsigned idx = 0;
     if (w.dense) {
@@ -184,11 +185,13 @@ __device__ __forceinline__ void preprocess_body(const PreArgs& a) {
         __syncthreads();
         if (has)
             for (int y = y0; y < y1; ++y)
-                for (int x = x0; x < x1; ++x, ++idx)
-                    if (ggs_tile_reachable(fp, x, y, c0, c1)) {
+                for (int x = x0; x < x1; ++x, ++idx) {
+                    const unsigned qm = ggs_quad_bits(fp, out.bbx, out.bby, x, y, c0, c1);
+                    if (qm) {
                         atomicAdd(&s_cnt[(y - w.y0) * w.w + (x - w.x0)], 1u);
-                        if (idx < GGS_TILE_BITS_MAX) bits |= 1ull << idx;
+                        if (idx < GGS_TILE_BITS_MAX) bits |= (unsigned long long)qm << (GGS_NQ * idx);
                     }
+                }
         __syncthreads();
         for (int i = threadIdx.x; i < area; i += 256) {
             const uint32_t c = s_cnt[i];
@@ -196,11 +199,13 @@ __device__ __forceinline__ void preprocess_body(const PreArgs& a) {
         }
     } else if (has) {
         for (int y = y0; y < y1; ++y)
-            for (int x = x0; x < x1; ++x, ++idx)
-                if (ggs_tile_reachable(fp, x, y, c0, c1)) {
+            for (int x = x0; x < x1; ++x, ++idx) {
+                const unsigned qm = ggs_quad_bits(fp, out.bbx, out.bby, x, y, c0, c1);
+                if (qm) {
                     atomicAdd(&cnt[y * gx + x], 1u);
-                    if (idx < GGS_TILE_BITS_MAX) bits |= 1ull << idx;
+                    if (idx < GGS_TILE_BITS_MAX) bits |= (unsigned long long)qm << (GGS_NQ * idx);
                 }
+            }
     }
     if (has) a.aux[vg].tile_bits = bits;
 }
@@ -251,9 +256,12 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
     const uint32_t* off = a.tile_offset + (size_t)v * a.T;
     unsigned long long* keys = a.keys + a.view_base[v];
     const TileWindow w = block_tile_window(s_box, has, x0, y0, x1, y1);
-    // membership of tile (x, y) = bit of the mask the preprocess pass stored (rects of <= 64 tiles), else re-tested
+    // sub-block mask of tile (x, y) (0 = not a member) = the bits the preprocess pass stored (rects of <= GGS_TILE_BITS_MAX tiles), else
+    // re-tested with the same function on the same record fields
     const bool small = (x1 - x0) * (y1 - y0) <= GGS_TILE_BITS_MAX;
-    auto member = [&](unsigned idx, int x, int y) { return small ? ((bits >> idx) & 1ull) != 0 : ggs_tile_reachable(fp, x, y, c0, c1); };
+    auto member = [&](unsigned idx, int x, int y) -> unsigned {
+        return small ? (unsigned)(bits >> (GGS_NQ * idx)) & ((1u << GGS_NQ) - 1u) : ggs_quad_bits(fp, bbx, bby, x, y, c0, c1);
+    };
     unsigned idx = 0;
     if (w.dense) {
         // count in LDS -> one returning global atomic per touched tile claims the workgroup's run of
@@ -279,19 +287,19 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
         if (has)
             for (int y = y0; y < y1; ++y)
                 for (int x = x0; x < x1; ++x, ++idx) {
-                    if (!member(idx, x, y)) continue;
-                    const unsigned long long qm = ggs_quad_mask(fp, bbx, bby, x, y, c0, c1);
+                    const unsigned qm = member(idx, x, y);
+                    if (!qm) continue;
                     const int i = (y - w.y0) * w.w + (x - w.x0);
-                    keys[(size_t)s_base[i] + atomicAdd(&s_cnt[i], 1u)] = key | (qm >> GGS_ID_BITS);
+                    keys[(size_t)s_base[i] + atomicAdd(&s_cnt[i], 1u)] = key | qm;
                 }
     } else if (has) {
         for (int y = y0; y < y1; ++y)
             for (int x = x0; x < x1; ++x, ++idx) {
-                if (!member(idx, x, y)) continue;
-                const unsigned long long qm = ggs_quad_mask(fp, bbx, bby, x, y, c0, c1);
+                const unsigned qm = member(idx, x, y);
+                if (!qm) continue;
                 const int t = y * a.gx + x;
                 const uint32_t slot = atomicAdd(&cur[t], 1u);
-                keys[(size_t)off[t] + slot] = key | (qm >> GGS_ID_BITS);
+                keys[(size_t)off[t] + slot] = key | qm;
             }
     }
 }
