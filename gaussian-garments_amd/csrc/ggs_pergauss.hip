@@ -242,10 +242,13 @@ __global__ __launch_bounds__(256) void ggs_k_scatter(ScatterArgs a) {
             const float4 r0 = reinterpret_cast<const float4*>(rec)[0];
             const float4 r2 = reinterpret_cast<const float4*>(rec)[2];
             ggs_tile_rect(r0.x, r0.y, (float)radius, a.gx16, a.gy, x0, y0, x1, y1);
-            const float4 r1 = reinterpret_cast<const float4*>(rec)[1];
             bbx = __float_as_uint(r2.z); bby = __float_as_uint(r2.w);
-            fp = ggs_footprint(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
             ggs_cull_rect(bbx, bby, x0, y0, x1, y1);
+            // the footprint (a logarithm, two divisions) only where the stored bits do not cover the rectangle: large splats
+            if ((x1 - x0) * (y1 - y0) > GGS_TILE_BITS_MAX) {       // (16-pixel columns here: at least as many as tile columns)
+                const float4 r1 = reinterpret_cast<const float4*>(rec)[1];
+                fp = ggs_footprint(r0.x, r0.y, r0.z, r0.w, r1.x, r1.y);
+            }
             key = ((unsigned long long)__float_as_uint(r2.y) << 32) | ((unsigned)g << GGS_NQ);   // low bits: sub-block mask
             has = x0 < x1 && y0 < y1;
         }
