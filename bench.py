@@ -580,17 +580,22 @@ def run(args, stage):
         traffic, traffic_src = None, None
         bid = _lib.build_id()
         views_per_launch = n_mine / launches
-        for fn in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.json")), reverse=True):
+        # (several collections of one build can match -- 32 views per launch, a single view: the launch shape closest to this run's
+        # is the one to scale from; a single-view launch runs the latency mapping, other kernels, other traffic)
+        best = None
+        for fn in sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_hbm_traffic.json")):
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", fn)))
                 wl = tj.get("workload", {})
                 if tj.get("build_id") == bid and wl == {"P": Fn, "W": W, "H": H, "sh_degree": args.sh_degree}:
-                    traffic = int(tj["kernels"]["ggs_k_" + dom + ("_sh%d" % args.sh_degree if dom == "preprocess_bwd" else "")]
-                                  ["traffic"] / tj["views_per_launch"] * views_per_launch)
-                    traffic_src = "profiles/" + fn
-                    break
+                    kname = "ggs_k_" + dom + ("_sh%d" % args.sh_degree if dom == "preprocess_bwd" else "")
+                    dist_ = abs(math.log(tj["views_per_launch"] / views_per_launch))
+                    if kname in tj["kernels"] and (best is None or dist_ < best[0]):
+                        best = (dist_, int(tj["kernels"][kname]["traffic"] / tj["views_per_launch"] * views_per_launch), "profiles/" + fn)
             except Exception:
                 continue
+        if best is not None:
+            traffic, traffic_src = best[1], best[2]
         # VALU occupancy of the same kernel from the committed PMC collection of this build (tools/profile_all.sh, pass "valu"):
         # the render kernels are bound by VALU issue, not by the HBM pipe the contract prices them against
         valu = None
