@@ -194,10 +194,17 @@ def test_one_view_against_the_c_oracle(scene):
     assert rel_l1(color[0].cpu(), co.color) <= REL_L1_TOL
     assert rel_l1(depth[0].cpu(), co.depth.reshape(H, W)) <= REL_L1_TOL
     assert rel_l1(alpha[0].cpu(), co.alpha.reshape(H, W)) <= REL_L1_TOL
+    errs = {}
     for k, ok in (("means3D", "means3D"), ("opacities", "opacities"), ("colors_precomp", "colors"), ("scales", "scales"),
                   ("rotations", "rotations")):
-        assert rel_l1(gr[k].cpu().reshape(og[ok].shape), og[ok]) <= REL_L1_TOL, k
-    assert rel_l1(gr["means2D"][0].cpu().reshape(og["means2D"].shape), og["means2D"]) <= REL_L1_TOL
+        errs[k] = rel_l1(gr[k].cpu().reshape(og[ok].shape), og[ok])
+    errs["means2D"] = rel_l1(gr["means2D"][0].cpu().reshape(og["means2D"].shape), og["means2D"])
+    # (the single-view backward is the SEGMENTED one: every segment starts from the forward's {T, C} checkpoints)
+    print("\n[config 2, one 1080p view, segmented backward] gradients vs the C oracle, relative L1:", {k: f"{v:.2e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v <= REL_L1_TOL, (k, v)
+    # ... and far inside the bar: the checkpoints cost no accuracy that could be told from the float atomics' own noise
+    assert max(errs.values()) <= 2e-5, errs
     co.close()
 
 
