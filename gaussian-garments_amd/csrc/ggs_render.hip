@@ -23,6 +23,10 @@
 // ~45 cycles of per-entry overhead + ~115 per active quadrant (1.6-1.9 per entry) + ~60 for the reduction; forward ~44 per visited
 // quadrant (2.09 per entry) + ~40 per blended one.  Round 5 (profiles/r05_pipeline_overlap.md): run side by side on two streams the
 // two kernels DO interleave and each slows down by what the other takes -- there is no idle issue slot for a second kernel to use.
+// Launches too small to fill the chip (a single view: ~1 100 non-empty tiles for 1 024 SIMDs) take the LATENCY mapping: the forward
+// one wave per (tile, quadrant) with two entries per pass (render_fwd_quadwave), which also leaves {T, C} checkpoints in front of every
+// round; the backward this same tile-wave body per SEGMENT of 64 list positions, started from those checkpoints (round 6,
+// ggs_common.h GGS_SEG; only a backward with depth / alpha gradients still walks whole lists, per quadrant, two entries per pass).
 // Mappings examined and not adopted (splat-major / systolic, larger tiles, MFMA moments, mod-8 lane folding, deferred / all-LDS
 // reductions): profiles/r03_bwd_mapping_study.md, r04_bwd_variants.md.  The variants that were BUILT for those measurements (the
 // permlane-swap butterfly of rounds 1-3, the all-values-through-LDS reduction, what-if builds that drop a stage and compute
@@ -61,7 +65,8 @@ __device__ __forceinline__ bool store_empty_tile(const RenderArgs& a, int v, int
 // K4b body.  NQ = 4: one wave per tile, lane = 4 pixels (one per quadrant) -- the throughput mapping.
 // (The latency mapping for launches too small to fill the chip -- one wave per (tile, quadrant), grid 4x larger:
 // a single view has ~1.1k non-empty tiles of ~300 splats for 1024 SIMDs and is bounded by the serial walk of its
-// longest tile -- is render_fwd_quadwave below; the backward keeps both mappings in one template.)
+// longest tile -- is render_fwd_quadwave below; the backward template holds both walks: NQ = 4 per tile or per (tile, segment),
+// NQ = 1 per (tile, quadrant) for the depth / alpha case.)
 // Same arithmetic per pixel, bit-identical results.
 // CENSUS (ggs_k_count_forward_visits, a diagnostic: bench.py's evaluated-against-blended pair counts): the same walk with the
 // same tests on the lists as the binning left them, nothing stored -- it counts the quadrant passes it makes instead.
